@@ -1,0 +1,146 @@
+"""ctypes binding of libmcport.so (C ABI: include/mcport.h).
+
+The library is the product's only compute path: if it is missing or cannot be loaded this module
+raises -- there is no NumPy/CPU fallback (a silent fallback would void every parity claim).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmcport.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+MCP_ABI_VERSION = 1
+MCP_MAX_ASSETS = 64
+MCP_SELECT_BINS = 2048
+MCP_COMPOUND = {"simple": 0, "log": 1}
+MCP_FLAG_NATIVE_MATH = 1
+(WS_PARTIALS, WS_MOMENTS, WS_STATE, WS_HIST, WS_QUANT, WS_TAIL_PARTIAL, WS_TAIL, WS_STATS) = range(8)
+
+
+class McpError(RuntimeError):
+    """Raised for any negative return code of the C ABI; carries mcp_last_error()."""
+
+
+class McpParams(ctypes.Structure):
+    _fields_ = [
+        ("n_assets", ctypes.c_int32), ("n_steps", ctypes.c_int32), ("n_portfolios", ctypes.c_int32),
+        ("compounding", ctypes.c_int32), ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("v0", ctypes.c_double), ("alpha", ctypes.c_double), ("rf", ctypes.c_double),
+    ]
+
+
+class McpStats(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_uint64), ("n_tail", ctypes.c_uint64), ("mean", ctypes.c_double), ("m2", ctypes.c_double),
+        ("std", ctypes.c_double), ("sharpe", ctypes.c_double), ("var", ctypes.c_double), ("cvar", ctypes.c_double),
+        ("min", ctypes.c_double), ("max", ctypes.c_double), ("sum_tail", ctypes.c_double),
+        ("x_lo", ctypes.c_double), ("x_hi", ctypes.c_double),
+    ]
+
+
+STATS_DTYPE = np.dtype([
+    ("n", np.uint64), ("n_tail", np.uint64), ("mean", np.float64), ("m2", np.float64), ("std", np.float64),
+    ("sharpe", np.float64), ("var", np.float64), ("cvar", np.float64), ("min", np.float64), ("max", np.float64),
+    ("sum_tail", np.float64), ("x_lo", np.float64), ("x_hi", np.float64),
+])
+assert STATS_DTYPE.itemsize == ctypes.sizeof(McpStats)
+
+MOMENTS_DTYPE = np.dtype([("n", np.float64), ("sum", np.float64), ("sumsq", np.float64),
+                          ("min", np.float64), ("max", np.float64)])
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_vp = ctypes.c_void_p
+_u64 = ctypes.c_uint64
+_int = ctypes.c_int
+_PP = ctypes.POINTER(McpParams)
+
+# every symbol include/mcport.h declares: (restype, argtypes)
+SIGNATURES = {
+    "mcp_abi_version": (_int, []),
+    "mcp_device_count": (_int, []),
+    "mcp_last_error": (ctypes.c_char_p, []),
+    "mcp_ctx_create": (_int, [_int, ctypes.POINTER(_vp)]),
+    "mcp_ctx_destroy": (None, [_vp]),
+    "mcp_simulate": (_int, [_vp, _PP, _f32p, _f32p, _f32p, _u64, _u64, _u64, _vp, _vp]),
+    "mcp_ws_bytes": (ctypes.c_size_t, [_int, _int, _int]),
+    "mcp_packed_len": (ctypes.c_size_t, [_int, _int]),
+    "mcp_pack_params": (_int, [_int, _int, _f32p, _f32p, _f32p, _f32p, ctypes.c_size_t]),
+    "mcp_paths_grid": (_int, [_PP, _u64]),
+    "mcp_launch_paths": (_int, [_PP, _vp, _u64, _u64, _u64, _vp, _u64, _vp, _int, _vp]),
+    "mcp_launch_moments": (_int, [_int, _vp, _int, _vp, _vp]),
+    "mcp_percentile_rank": (_int, [_u64, ctypes.c_double, ctypes.POINTER(_u64), ctypes.POINTER(_u64),
+                                   ctypes.POINTER(ctypes.c_double)]),
+    "mcp_launch_select_init": (_int, [_int, _u64, _u64, _vp, _vp]),
+    "mcp_launch_select_hist": (_int, [_int, _vp, _u64, _u64, _int, _vp, _vp, _vp]),
+    "mcp_launch_select_scan": (_int, [_int, _int, _vp, _vp, _vp]),
+    "mcp_launch_quantile": (_int, [_PP, ctypes.c_double, _vp, _vp, _vp]),
+    "mcp_launch_tail": (_int, [_PP, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "mcp_launch_stats": (_int, [_PP, _vp, _vp, _vp, _vp, _vp]),
+    "mcp_float_to_key": (ctypes.c_uint32, [ctypes.c_float]),
+    "mcp_key_to_float": (ctypes.c_float, [ctypes.c_uint32]),
+    "mcp_terminal_to_x": (ctypes.c_double, [_PP, ctypes.c_float]),
+}
+
+_LIB = None
+
+
+def build(force: bool = False, jobs: int = 8) -> str:
+    """Compile libmcport.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, f"-j{jobs}"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libmcport.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C {CSRC} -j8` (or __graft_entry__.build()). "
+                "There is no CPU fallback for the path engine.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        got = L.mcp_abi_version()
+        if got != MCP_ABI_VERSION:
+            raise ImportError(f"libmcport.so ABI {got} != binding ABI {MCP_ABI_VERSION}; rebuild")
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise McpError(f"libmcport error {rc}: {lib().mcp_last_error().decode('utf-8', 'replace')}")
+    return rc
+
+
+def make_params(n_assets, n_steps, n_portfolios, compounding="simple", v0=1.0, alpha=0.95, rf=0.0,
+                native_math=False) -> McpParams:
+    if compounding not in MCP_COMPOUND:
+        raise ValueError(f"compounding must be 'simple' or 'log', got {compounding!r}")
+    return McpParams(int(n_assets), int(n_steps), int(n_portfolios), MCP_COMPOUND[compounding],
+                     MCP_FLAG_NATIVE_MATH if native_math else 0, 0, float(v0), float(alpha), float(rf))
+
+
+def pack_params(mu: np.ndarray, chol: np.ndarray, W: np.ndarray) -> np.ndarray:
+    n = mu.shape[0]
+    k = W.shape[0]
+    out = np.zeros(lib().mcp_packed_len(n, k), np.float32)
+    check(lib().mcp_pack_params(n, k, mu, chol, W, out, out.size))
+    return out
+
+
+def percentile_rank(n_total: int, alpha: float):
+    lo, hi, g = _u64(), _u64(), ctypes.c_double()
+    check(lib().mcp_percentile_rank(n_total, alpha, ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(g)))
+    return lo.value, hi.value, g.value

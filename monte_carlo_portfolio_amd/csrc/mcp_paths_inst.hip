@@ -1,0 +1,35 @@
+// mcp_paths_inst.hip -- instantiates mc_paths_kernel for ONE value of NB (= ceil(N/4), -DMCP_NB=n).
+// Built once per NB in 1..16 so the 16 translation units compile in parallel (see Makefile).
+#include "mcp_paths.h"
+#include "mcp_stats_kernels.h"
+
+#ifndef MCP_NB
+#error "compile with -DMCP_NB=<1..16>"
+#endif
+
+#define MCP_CAT_(a, b) a##b
+#define MCP_CAT(a, b) MCP_CAT_(a, b)
+
+namespace mcp {
+
+template <int KT, int PPT, bool NATIVE>
+static hipError_t go(const PathArgs& args, int grid, hipStream_t stream) {
+  mc_paths_kernel<MCP_NB, KT, PPT, NATIVE><<<grid, PATH_BLOCK, 0, stream>>>(args);
+  return hipGetLastError();
+}
+
+hipError_t MCP_CAT(launch_paths_nb, MCP_NB)(int variant, const PathArgs& args, int grid, hipStream_t stream) {
+  switch (variant) {
+    case 0: return go<1, 1, false>(args, grid, stream);
+    case VAR_NATIVE: return go<1, 1, true>(args, grid, stream);
+    case VAR_KT8: return go<8, 1, false>(args, grid, stream);
+    case VAR_KT8 | VAR_NATIVE: return go<8, 1, true>(args, grid, stream);
+#if MCP_NB <= 4
+    case VAR_PPT2: return go<1, 2, false>(args, grid, stream);
+    case VAR_PPT2 | VAR_NATIVE: return go<1, 2, true>(args, grid, stream);
+#endif
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace mcp

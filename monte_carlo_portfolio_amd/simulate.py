@@ -1,0 +1,109 @@
+"""simulate_paths: the Monte Carlo path simulator behind the Streamlit-shaped surface.
+
+Replaces, for a *simulated* terminal-value distribution, what the reference computes per portfolio
+on *historical* returns at app.py:708-713 (portfolio mean/vol, Sharpe, 5 % VaR, CVaR).  Inputs are
+the same objects the reference builds at app.py:679-680 (mean vector, covariance matrix), here per
+step.  All arithmetic on the path happens in libmcport.so's HIP kernels (SPEC.md); this module only
+validates, factors Sigma (float64 Cholesky on the host, cast to fp32) and marshals arrays.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+
+import numpy as np
+
+from . import _ffi
+
+_CTX_LOCK = threading.Lock()
+_CTX: dict[int, "Context"] = {}
+
+
+class Context:
+    """Owns one mcp_ctx (device buffers + stream) on one GPU.  Calls are serialised by the library."""
+
+    def __init__(self, device: int = 0):
+        self._h = ctypes.c_void_p()
+        _ffi.check(_ffi.lib().mcp_ctx_create(device, ctypes.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            _ffi.lib().mcp_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def simulate(self, prm: _ffi.McpParams, mu, chol, W, seed: int, path_begin: int, n_paths: int, store: bool):
+        K = prm.n_portfolios
+        stats = np.zeros(K, _ffi.STATS_DTYPE)
+        term = np.empty((K, n_paths), np.float32) if store else None
+        _ffi.check(_ffi.lib().mcp_simulate(
+            self._h, ctypes.byref(prm), mu, chol, W, seed, path_begin, n_paths,
+            term.ctypes.data_as(ctypes.c_void_p) if store else None,
+            stats.ctypes.data_as(ctypes.c_void_p)))
+        return stats, term
+
+
+def default_context(device: int = 0) -> Context:
+    with _CTX_LOCK:
+        if device not in _CTX:
+            _CTX[device] = Context(device)
+        return _CTX[device]
+
+
+def cholesky_factor(cov: np.ndarray) -> np.ndarray:
+    """Lower Cholesky factor of Sigma, float64 -> float32.  Raises ValueError if Sigma is not PD
+    (e.g. fewer return rows than assets)."""
+    cov = np.asarray(cov, np.float64)
+    if cov.ndim != 2 or cov.shape[0] != cov.shape[1]:
+        raise ValueError(f"cov must be square, got {cov.shape}")
+    try:
+        L = np.linalg.cholesky(cov)
+    except np.linalg.LinAlgError as e:
+        raise ValueError(f"covariance matrix is not positive definite: {e}") from None
+    return np.ascontiguousarray(L, np.float32)
+
+
+def prepare_inputs(mu, cov, weights, chol=None):
+    mu = np.ascontiguousarray(mu, np.float32).ravel()
+    n = mu.shape[0]
+    if not 1 <= n <= _ffi.MCP_MAX_ASSETS:
+        raise ValueError(f"n_assets={n} outside [1, {_ffi.MCP_MAX_ASSETS}]")
+    L = cholesky_factor(cov) if chol is None else np.ascontiguousarray(np.tril(chol), np.float32)
+    if L.shape != (n, n):
+        raise ValueError(f"cov/chol shape {L.shape} does not match mu ({n})")
+    W = np.ascontiguousarray(np.atleast_2d(np.asarray(weights, np.float32)))
+    if W.shape[1] != n:
+        raise ValueError(f"weights have {W.shape[1]} columns, expected {n}")
+    return mu, L, W
+
+
+def stats_to_dict(rec) -> dict:
+    return {name: (int(rec[name]) if name in ("n", "n_tail") else float(rec[name])) for name in rec.dtype.names}
+
+
+def simulate_paths(mu, cov, weights, n_steps=252, n_paths=10_000, seed=0, v0=1.0, compounding="simple",
+                   rf=0.0, alpha=0.95, devices=None, store=False, path_begin=0, chol=None,
+                   native_math=False):
+    """Simulate `n_paths` correlated return paths and reduce them to risk statistics.
+
+    mu [N], cov [N,N] are per-step mean and covariance (the reference's `mean_returns`, `cov_matrix`
+    of app.py:679-680 divided by `annual_factor`); weights [N] or [K,N].  Returns a dict for a single
+    weight vector or a list of dicts (plus key 'opt_idx' handled by run_sweep) for K portfolios; with
+    store=True the dict carries 'terminal' (float32 [n_paths] or [K, n_paths]).
+    """
+    single = np.asarray(weights).ndim == 1
+    mu32, L, W = prepare_inputs(mu, cov, weights, chol)
+    prm = _ffi.make_params(mu32.shape[0], n_steps, W.shape[0], compounding, v0, alpha, rf, native_math)
+    dev = 0 if not devices else int(devices[0])
+    stats, term = default_context(dev).simulate(prm, mu32, L, W, int(seed), int(path_begin), int(n_paths), store)
+    out = [stats_to_dict(stats[k]) for k in range(W.shape[0])]
+    if store:
+        for k, d in enumerate(out):
+            d["terminal"] = term[k]
+    return out[0] if single else out

@@ -1,0 +1,230 @@
+/*
+ * mc_oracle.c -- CPU restatement (ORACLE, test infrastructure only) of the Monte Carlo path
+ * simulator frozen in SPEC.md ("MC-A").
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may build, load or call it.  The product (libmcport.so) never links it.
+ *
+ * PARITY STATUS: "parity unpinned" against reference *code* for the path simulator itself: the
+ * reference (/root/reference/app.py) contains no Cholesky / normal-draw / path loop at all
+ * (SURVEY.md section 0.2).  What the reference does pin, and what this file follows, are the
+ * conventions:
+ *   - portfolio return of a fixed-weight portfolio  rho = returns @ w      app.py:710
+ *   - compounding  prod(1 + r) / cumprod(1 + r)                            app.py:249, app.py:253
+ *   - mu / Sigma parameterisation  returns.mean(), returns.cov()           app.py:679-680
+ * The integer RNG stream (Philox4x32-10) IS pinned: against the Random123 known-answer vectors
+ * and against rocRAND's host-callable engine (/opt/rocm/include/rocrand/rocrand_philox4x32_10.h:
+ * 270-296), see tests/test_oracle_rng.py.  The statistics (VaR/CVaR/Sharpe) are computed by
+ * oracle/ref_stats.py, which follows app.py:258-263 and app.py:711 and is pinned by goldens
+ * generated from the reference itself (tests/golden/).
+ *
+ * Everything here is IEEE-754 binary32 with round-to-nearest-even, explicit fmaf(), and
+ * correctly rounded sqrtf(); compile with -ffp-contract=off so the compiler adds no fusions of
+ * its own.  The HIP kernel executes the same operations in the same order, so terminal values
+ * are compared BIT-EXACTLY.
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MCO_MAX_ASSETS 64
+
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(MCO_NO_CLONES)
+#define MCO_CLONES __attribute__((target_clones("avx2,fma", "default")))
+#else
+#define MCO_CLONES
+#endif
+#define MCO_INLINE static inline __attribute__((always_inline))
+
+/* ---- Philox4x32-10 (Salmon et al., SC'11; Random123).  Same constants / round function as
+ *      rocRAND rocrand_philox4x32_10.h:62-65, 287-296. ---------------------------------------- */
+#define PHILOX_M0 0xD2511F53u
+#define PHILOX_M1 0xCD9E8D57u
+#define PHILOX_W0 0x9E3779B9u
+#define PHILOX_W1 0xBB67AE85u
+
+MCO_INLINE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                              uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += PHILOX_W0; k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+MCO_INLINE float u32_as_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+MCO_INLINE uint32_t f32_as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* ---- Box-Muller pair, SPEC.md section 3.  Coefficients: tools/fit_coeffs.py. ---------------- */
+/* -2*log1p(f) = -2 f + f^2 Q(f),  f in [sqrt(.5)-1, sqrt(2)-1],  Q degree 7 */
+#define LQ0  0x1.fffff4p-1f
+#define LQ1 -0x1.5557acp-1f
+#define LQ2  0x1.000688p-1f
+#define LQ3 -0x1.98a664p-2f
+#define LQ4  0x1.52fdf6p-2f
+#define LQ5 -0x1.32c6c8p-2f
+#define LQ6  0x1.27c4a8p-2f
+#define LQ7 -0x1.65b8e2p-3f
+#define NEG_2LN2 -0x1.62e43p+0f          /* -2 ln 2 rounded to binary32 */
+/* sin(a) = a + a^3 S(a^2), cos(a) = 1 - a^2/2 + a^4 C(a^2), |a| <= pi/4 */
+#define SS0 -0x1.55554p-3f
+#define SS1  0x1.1105b4p-7f
+#define SS2 -0x1.98da62p-13f
+#define CC0  0x1.55554ap-5f
+#define CC1 -0x1.6c0c8cp-10f
+#define CC2  0x1.9a0256p-16f
+#define TWO_PI_2M32 0x1.921fb6p-30f      /* 2 pi / 2^32 rounded to binary32 */
+
+MCO_INLINE void box_muller(uint32_t xa, uint32_t xb, float *z_sin, float *z_cos)
+{
+    /* radius: u in [2^-32, 1] */
+    float u = fmaf((float)xa, 0x1p-32f, 0x1p-32f);
+    uint32_t ib = f32_as_u32(u) - 0x3f3504f3u;              /* sqrt(.5) split */
+    int32_t k = (int32_t)ib >> 23;
+    float m = u32_as_f32((ib & 0x007fffffu) + 0x3f3504f3u);  /* [sqrt(.5), sqrt(2)) */
+    float f = m - 1.0f;
+    float q = LQ7;
+    q = fmaf(q, f, LQ6); q = fmaf(q, f, LQ5); q = fmaf(q, f, LQ4); q = fmaf(q, f, LQ3);
+    q = fmaf(q, f, LQ2); q = fmaf(q, f, LQ1); q = fmaf(q, f, LQ0);
+    float ff = f * f;
+    float tm = fmaf(f, -2.0f, ff * q);                       /* -2 log(m) */
+    float t = fmaf((float)k, NEG_2LN2, tm);                  /* -2 log(u) >= 0 */
+    float s = sqrtf(t);
+    /* angle: theta = 2 pi xb / 2^32 = kq*pi/2 + a, |a| <= pi/4, exact integer reduction */
+    uint32_t y = xb + 0x20000000u;
+    int32_t r = (int32_t)(xb << 2) >> 2;                     /* xb - kq*2^30, in [-2^29, 2^29) */
+    float a = (float)r * TWO_PI_2M32;
+    float a2 = a * a;
+    float ps = fmaf(a2, SS2, SS1); ps = fmaf(a2, ps, SS0);
+    float sn = fmaf(a * a2, ps, a);
+    float pc = fmaf(a2, CC2, CC1); pc = fmaf(a2, pc, CC0);
+    float cs = fmaf(a2 * a2, pc, fmaf(a2, -0.5f, 1.0f));
+    uint32_t swap = y & 0x40000000u;                         /* kq odd */
+    float vs = swap ? cs : sn;
+    float vc = swap ? sn : cs;
+    uint32_t sign_s = y & 0x80000000u;                       /* kq in {2,3} */
+    uint32_t sign_c = (y ^ (y << 1)) & 0x80000000u;          /* kq in {1,2} */
+    *z_sin = u32_as_f32(f32_as_u32(s) ^ sign_s) * vs;
+    *z_cos = u32_as_f32(f32_as_u32(s) ^ sign_c) * vc;
+}
+
+/* normals of one path-step: z[m*nb + q] = normal m of Philox block q   (SPEC.md section 2) */
+MCO_INLINE void step_normals(uint32_t k0, uint32_t k1, uint64_t path, uint32_t step, int nb, float *z)
+{
+    for (int q = 0; q < nb; q++) {
+        uint64_t blk = (uint64_t)step * (uint32_t)nb + (uint32_t)q;
+        uint32_t x[4];
+        philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)path, (uint32_t)(path >> 32), k0, k1, x);
+        box_muller(x[0], x[1], &z[0 * nb + q], &z[1 * nb + q]);
+        box_muller(x[2], x[3], &z[2 * nb + q], &z[3 * nb + q]);
+    }
+}
+
+/* ---- exported small pieces (unit-tested against known answers) ------------------------------ */
+void mco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+void mco_box_muller(uint32_t xa, uint32_t xb, float *z_sin, float *z_cos)
+{
+    box_muller(xa, xb, z_sin, z_cos);
+}
+
+/* n pairs at once (vector form for the accuracy tests) */
+MCO_CLONES
+void mco_box_muller_n(const uint32_t *xa, const uint32_t *xb, float *z_sin, float *z_cos, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; i++) box_muller(xa[i], xb[i], &z_sin[i], &z_cos[i]);
+}
+
+MCO_CLONES
+void mco_step_normals(uint64_t seed, uint64_t path, uint32_t step, int n_assets, float *z /* [4*ceil(N/4)] */)
+{
+    int nb = (n_assets + 3) / 4;
+    step_normals((uint32_t)seed, (uint32_t)(seed >> 32), path, step, nb, z);
+}
+
+/* ---- the path loop --------------------------------------------------------------------------- */
+typedef struct {
+    int n_assets, n_steps, n_portfolios, compounding;   /* compounding: 0 simple, 1 log-sum */
+    float v0;
+    const float *mu, *chol, *W;
+    uint64_t seed, path_begin, n_paths, p_lo, p_hi;
+    float *terminal;                                     /* [K][n_paths] */
+} mco_job;
+
+MCO_CLONES
+static void simulate_range(const mco_job *j)
+{
+    const int N = j->n_assets, K = j->n_portfolios, T = j->n_steps;
+    const int nb = (N + 3) / 4, N4 = 4 * nb;
+    const uint32_t k0 = (uint32_t)j->seed, k1 = (uint32_t)(j->seed >> 32);
+    float L[MCO_MAX_ASSETS * MCO_MAX_ASSETS], mu[MCO_MAX_ASSETS];
+    float z[MCO_MAX_ASSETS], r[MCO_MAX_ASSETS];
+    float *Wp = (float *)calloc((size_t)K * N4, sizeof(float));
+    float *V = (float *)malloc((size_t)K * sizeof(float));
+    memset(L, 0, sizeof(float) * N4 * N4);
+    memset(mu, 0, sizeof(float) * N4);
+    for (int i = 0; i < N; i++) {
+        mu[i] = j->mu[i] + 0.0f;                           /* -0 -> +0 */
+        for (int c = 0; c <= i; c++) L[i * N4 + c] = j->chol[i * N + c];
+    }
+    for (int k = 0; k < K; k++)
+        for (int i = 0; i < N; i++) Wp[k * N4 + i] = j->W[k * N + i];
+
+    for (uint64_t p = j->p_lo; p < j->p_hi; p++) {
+        const uint64_t path = j->path_begin + p;
+        for (int k = 0; k < K; k++) V[k] = j->compounding ? 0.0f : j->v0;
+        for (int t = 0; t < T; t++) {
+            step_normals(k0, k1, path, (uint32_t)t, nb, z);
+            for (int i = 0; i < N4; i++) {                  /* r = mu + L z, j ascending, fma */
+                float acc = mu[i];
+                for (int c = 0; c <= i; c++) acc = fmaf(L[i * N4 + c], z[c], acc);
+                r[i] = acc;
+            }
+            for (int k = 0; k < K; k++) {                   /* rho = w . r, i ascending, fma */
+                float rho = 0.0f;
+                for (int i = 0; i < N4; i++) rho = fmaf(Wp[k * N4 + i], r[i], rho);
+                if (j->compounding) V[k] = V[k] + rho;      /* S += rho */
+                else V[k] = fmaf(V[k], rho, V[k]);          /* V *= (1 + rho) */
+            }
+        }
+        for (int k = 0; k < K; k++) j->terminal[(size_t)k * j->n_paths + p] = V[k];
+    }
+    free(Wp); free(V);
+}
+
+static void *worker(void *arg) { simulate_range((const mco_job *)arg); return NULL; }
+
+/* returns 0 on success, <0 on bad arguments */
+int mco_simulate(int n_assets, int n_steps, int n_portfolios, int compounding, float v0,
+                 const float *mu, const float *chol /* [N*N] row-major lower */,
+                 const float *W /* [K*N] */, uint64_t seed, uint64_t path_begin, uint64_t n_paths,
+                 float *terminal /* [K*n_paths] */, int n_threads)
+{
+    if (n_assets < 1 || n_assets > MCO_MAX_ASSETS || n_steps < 0 || n_portfolios < 1) return -1;
+    if (n_threads < 1) n_threads = 1;
+    if ((uint64_t)n_threads > n_paths) n_threads = n_paths ? (int)n_paths : 1;
+    mco_job *jobs = (mco_job *)malloc(sizeof(mco_job) * n_threads);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * n_threads);
+    for (int i = 0; i < n_threads; i++) {
+        mco_job jb = {n_assets, n_steps, n_portfolios, compounding, v0, mu, chol, W, seed, path_begin,
+                      n_paths, n_paths * i / n_threads, n_paths * (i + 1) / n_threads, terminal};
+        jobs[i] = jb;
+    }
+    for (int i = 1; i < n_threads; i++) pthread_create(&th[i], NULL, worker, &jobs[i]);
+    simulate_range(&jobs[0]);
+    for (int i = 1; i < n_threads; i++) pthread_join(th[i], NULL);
+    free(jobs); free(th);
+    return 0;
+}
