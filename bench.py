@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: simulated paths/s at 16 assets x 252 steps (+ VaR
+abs-err vs the oracle), one process per GPU.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over one batch resident in HBM: fused path kernel
+(Philox -> Box-Muller -> Cholesky GEMV -> compounding) for BASELINE configs[1] per GPU (16 synthetic
+assets, 1,000,000 paths, 252 steps, fp32), then moments, exact VaR (3-pass radix select) and CVaR,
+with the cross-rank exchanges of SURVEY.md section 8(e) when N > 1.  Weak scaling: every rank simulates its
+own 1M-path shard of one global path range.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+N_ASSETS, N_STEPS, PATHS_PER_GPU = 16, 252, 1_000_000
+MODEL_FLOPS_PER_PATH = N_STEPS * (N_ASSETS * N_ASSETS + 3 * N_ASSETS + 2)     # 77,112
+HBM_BYTES_PER_PATH = 4                                                          # V_T store
+# VALU-issue ceiling of the unfolded model: per wave and path-step 80 widening
+# multiplies + 32 transcendentals + 329 full-rate ops at the issue costs measured on this chip at 8
+# waves/SIMD (profiles/r01_valu_rates.txt): 4.7, 8.2, 2.6 cycles -> 1,494 cycles; 1,024 SIMDs x 2.4 GHz.
+ISSUE_CYCLES_PER_WAVE_STEP = 80 * 4.7 + 32 * 8.2 + (120 + 56 + 153) * 2.6
+VALU_CEILING_PATHS_PER_S = 1024 * 2.4e9 * 64 / (ISSUE_CYCLES_PER_WAVE_STEP * N_STEPS)
+HBM_PEAK_GBS = 8000.0
+FP32_VECTOR_PEAK_TFLOPS = 157.3
+
+
+def cpu_baseline(mu32, L, W32, seed):
+    """The oracle (CPU port of the same spec) on this box's host cores, bounded to ~10-20 s."""
+    from oracle import mc_oracle
+    threads = min(os.cpu_count() or 1, 64)
+    t0 = time.perf_counter()
+    mc_oracle.simulate(mu32, L, W32, N_STEPS, 4096, seed, n_threads=threads)
+    rate = 4096 / (time.perf_counter() - t0)
+    n = int(min(max(rate * 12.0, 8192), 2_000_000))
+    t0 = time.perf_counter()
+    term = mc_oracle.simulate(mu32, L, W32, N_STEPS, n, seed, n_threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "paths/s", "cores": threads, "kind": "port",
+            "sample": f"{n} paths of the bench workload (16 assets x 252 steps, seed 0x5EED5EED), oracle/mc_oracle.c, {threads} threads"}, term
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--native-math", action="store_true", help="hardware log/sqrt/sin/cos Box-Muller (tolerance parity)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        group = dist.group.WORLD
+
+    from monte_carlo_portfolio_amd import synthetic
+    from monte_carlo_portfolio_amd.engine import PathEngine
+    from monte_carlo_portfolio_amd.simulate import prepare_inputs
+
+    mu, cov = synthetic.synthetic_market(N_ASSETS)
+    w = synthetic.equal_weights(N_ASSETS)
+    mu32, L, W32 = prepare_inputs(mu, cov, w)
+    seed = synthetic.BENCH_SEED
+    eng = PathEngine(mu32, L, W32, N_STEPS, PATHS_PER_GPU, group=group, world_size=world, rank=rank,
+                     native_math=args.native_math)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        eng.step(seed, path_base=0)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.step(seed, path_base=0)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stats = eng.stats()[0]
+
+    # dominant kernel alone, HIP events on the launch stream
+    n_k = 10
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    eng.launch_paths_only(seed)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(n_k):
+        eng.launch_paths_only(seed)
+    ev1.record()
+    torch.cuda.synchronize()
+    k_ms = ev0.elapsed_time(ev1) / n_k
+
+    if rank == 0:
+        total_paths = PATHS_PER_GPU * world * args.steps
+        value = total_paths / elapsed
+        k_paths_s = PATHS_PER_GPU / (k_ms * 1e-3)
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get("mc_paths_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "valu",
+            "kernel": "mc_paths_kernel<NB=4,KT=1>",
+            "achieved": MODEL_FLOPS_PER_PATH * k_paths_s / 1e12,
+            "peak": MODEL_FLOPS_PER_PATH * VALU_CEILING_PATHS_PER_S / 1e12,
+            "unit": "TFLOP/s",
+            "frac": k_paths_s / VALU_CEILING_PATHS_PER_S,
+            "traffic": traffic,
+            "kernel_ms": k_ms,
+            "kernel_paths_per_s": k_paths_s,
+            "note": "VALU-issue bound (SURVEY 0.4/8d): achieved/peak = model fp32 FLOPs (77,112/path) x paths/s; "
+                    "peak is the issue-cycle ceiling of the unfolded instruction mix at measured gfx950 issue costs, "
+                    "not the 157.3 TFLOP/s fp32 vector peak",
+            "frac_of_fp32_vector_peak": MODEL_FLOPS_PER_PATH * k_paths_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+            "hbm": {"achieved": HBM_BYTES_PER_PATH * k_paths_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": HBM_BYTES_PER_PATH * k_paths_s / 1e9 / HBM_PEAK_GBS},
+        }
+        out = {
+            "metric": "simulated paths/sec (16 assets x 252 steps) + VaR abs-err vs NumPy ref",
+            "value": value, "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 16 synthetic assets, 1,000,000 paths per GPU, 252 steps, fp32, "
+                                   "full pass = paths + moments + exact VaR/CVaR",
+                       "n_assets": N_ASSETS, "n_steps": N_STEPS, "paths_per_gpu": PATHS_PER_GPU,
+                       "global_paths": PATHS_PER_GPU * world, "parallelism": f"path-sharded x{world}",
+                       "math": "native" if args.native_math else "exact"},
+            "stats": {"mean": float(stats["mean"]), "std": float(stats["std"]), "sharpe": float(stats["sharpe"]),
+                      "var95": float(stats["var"]), "cvar95": float(stats["cvar"]), "n": int(stats["n"]),
+                      "n_tail": int(stats["n_tail"])},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, term = cpu_baseline(mu32, L, W32, seed)
+            out["cpu_baseline"] = base
+            # VaR abs-err vs the NumPy reference on identical seeds: same paths on both sides
+            from oracle import ref_stats
+            n = term.shape[1]
+            from monte_carlo_portfolio_amd import simulate_paths
+            g = simulate_paths(mu, cov, w, n_steps=N_STEPS, n_paths=n, seed=seed, native_math=args.native_math)
+            want = ref_stats.path_stats(term[0])
+            out["var_abs_err"] = abs(g["var"] - want["var"])
+            out["sharpe_rel_err"] = abs(g["sharpe"] - want["sharpe"]) / abs(want["sharpe"])
+            out["var_check_paths"] = n
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

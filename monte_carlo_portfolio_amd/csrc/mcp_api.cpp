@@ -194,11 +194,11 @@ int mcp_launch_moments(int K, const void* d_partials, int grid, void* d_moments,
 
 int mcp_percentile_rank(uint64_t n, double alpha, uint64_t* rank_lo, uint64_t* rank_hi, double* gamma) {
   if (n < 1 || !rank_lo || !rank_hi || !gamma) return fail(MCP_E_ARG, "bad argument");
-  // app.py:259  np.percentile(returns, (1-alpha)*100); numpy divides by 100 again, then
-  // _compute_virtual_index(n, q, 1, 1) = n*q + (1 + q*(1-1-1)) - 1 in this evaluation order.
+  // app.py:259  np.percentile(returns, (1-alpha)*100); numpy divides by 100 again, then method
+  // 'linear' takes virtual_index = (n - 1) * q  (numpy 2.2 _QuantileMethods['linear']).
   const double pct = (1.0 - alpha) * 100.0;
   const double q = pct / 100.0;
-  const double vi = (double)n * q + (1.0 + q * -1.0) - 1.0;
+  const double vi = (double)(n - 1) * q;
   if (vi >= (double)(n - 1)) { *rank_lo = *rank_hi = n - 1; *gamma = 0.0; return MCP_OK; }
   if (vi < 0.0) { *rank_lo = *rank_hi = 0; *gamma = 0.0; return MCP_OK; }
   const double fl = std::floor(vi);

@@ -1,0 +1,153 @@
+"""PathEngine: the device-level pipeline, one process per GPU, buffers resident in HBM.
+
+PyTorch is plumbing only here: it allocates the device buffers, provides the HIP stream the kernels
+are enqueued on, and carries the RCCL collectives (torch.distributed backend "nccl" on ROCm).  Every
+kernel is launched through libmcport.so's C ABI (include/mcport.h, mcp_launch_*) by `HipKernels`;
+nothing on the path is a torch op except the three-line merge of the gathered moments.
+
+Sharding: rank g simulates the global path range [g*P, (g+1)*P); the Philox
+counter carries the *global* path id, so any partition yields the same terminal values.  Exchanges
+per step:
+  - moments: one all_gather of [K] {n, sum, sumsq, min, max} (40 B per portfolio)
+  - VaR: 3 all_reduce(SUM) of the [K][2][2048] uint64 digit histograms of the radix select
+  - CVaR: one all_reduce(SUM) of [K] {count, sum}
+All are latency-bound; xGMI bandwidth is irrelevant at these sizes.
+
+The kernel launches sit behind the small `HipKernels` interface so that the collective choreography
+(the only multi-rank logic there is) can be exercised on CPU with world_size 2 over gloo by a test
+double (tests/fake_kernels.py); the product always uses HipKernels and fails without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _ffi
+
+
+class HipKernels:
+    """Enqueue-only launches of libmcport.so's kernels on torch's current HIP stream."""
+
+    device_type = "cuda"
+
+    def __init__(self, torch, device):
+        self.torch, self.device = torch, device
+        self.lib = _ffi.lib()
+        if self.lib.mcp_device_count() < 1:
+            raise _ffi.McpError("no HIP device visible (the product path has no CPU fallback)")
+
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def _p(t):
+        return ctypes.c_void_p(t.data_ptr())
+
+    def paths_grid(self, prm, n):
+        return _ffi.check(self.lib.mcp_paths_grid(ctypes.byref(prm), n))
+
+    def paths(self, prm, packed, seed, path_begin, n, terminal, partials, grid):
+        _ffi.check(self.lib.mcp_launch_paths(ctypes.byref(prm), self._p(packed), seed, path_begin, n,
+                                             self._p(terminal), terminal.shape[1], self._p(partials), grid,
+                                             self._stream()))
+
+    def moments(self, K, partials, grid, moments):
+        _ffi.check(self.lib.mcp_launch_moments(K, self._p(partials), grid, self._p(moments), self._stream()))
+
+    def select_init(self, K, lo, hi, state):
+        _ffi.check(self.lib.mcp_launch_select_init(K, lo, hi, self._p(state), self._stream()))
+
+    def select_hist(self, K, terminal, n, p, state, hist):
+        _ffi.check(self.lib.mcp_launch_select_hist(K, self._p(terminal), terminal.shape[1], n, p, self._p(state),
+                                                   self._p(hist), self._stream()))
+
+    def select_scan(self, K, p, hist, state):
+        _ffi.check(self.lib.mcp_launch_select_scan(K, p, self._p(hist), self._p(state), self._stream()))
+
+    def quantile(self, prm, gamma, state, quant):
+        _ffi.check(self.lib.mcp_launch_quantile(ctypes.byref(prm), gamma, self._p(state), self._p(quant), self._stream()))
+
+    def tail(self, prm, terminal, n, quant, tail_partial, tail):
+        _ffi.check(self.lib.mcp_launch_tail(ctypes.byref(prm), self._p(terminal), terminal.shape[1], n, self._p(quant),
+                                            self._p(tail_partial), self._p(tail), self._stream()))
+
+    def stats(self, prm, moments, quant, tail, stats):
+        _ffi.check(self.lib.mcp_launch_stats(ctypes.byref(prm), self._p(moments), self._p(quant), self._p(tail),
+                                             self._p(stats), self._stream()))
+
+
+class PathEngine:
+    def __init__(self, mu32, chol32, W32, n_steps, n_paths_local, *, compounding="simple", v0=1.0, alpha=0.95,
+                 rf=0.0, native_math=False, device=None, group=None, world_size=1, rank=0, kernels=None):
+        import torch
+
+        self.torch = torch
+        if kernels is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+            kernels = HipKernels(torch, device)
+        self.k = kernels
+        self.device = torch.device(device if device is not None else kernels.device_type)
+        self.group, self.world, self.rank = group, int(world_size), int(rank)
+        self.n_local = int(n_paths_local)
+        self.n_total = self.n_local * self.world
+        K = W32.shape[0]
+        self.K = K
+        self.prm = _ffi.make_params(mu32.shape[0], n_steps, K, compounding, v0, alpha, rf, native_math)
+        self.grid = self.k.paths_grid(self.prm, self.n_local)
+        self.rank_lo, self.rank_hi, self.gamma = _ffi.percentile_rank(self.n_total, alpha)
+
+        lib = _ffi.lib()
+        packed = _ffi.pack_params(mu32, chol32, W32)
+        self.d_packed = torch.from_numpy(packed).to(self.device)
+        self.d_terminal = torch.empty((K, self.n_local), dtype=torch.float32, device=self.device)
+        self.ws = {}
+        for which in range(8):
+            nbytes = lib.mcp_ws_bytes(which, K, self.grid)
+            self.ws[which] = torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=self.device)
+        # typed views for the collectives
+        self.moments = self.ws[_ffi.WS_MOMENTS].view(torch.float64).view(K, 5)
+        self.hist = self.ws[_ffi.WS_HIST]                                  # int64 counts [K][2][2048]
+        self.tail = self.ws[_ffi.WS_TAIL].view(torch.float64).view(K, 2)
+        if self.world > 1:
+            self._gather = torch.empty((self.world, K, 5), dtype=torch.float64, device=self.device)
+
+    def step(self, seed: int, path_base: int = 0):
+        """Enqueue one full pass (paths -> statistics) on the current stream.  No host sync."""
+        k, K, n, ws = self.k, self.K, self.n_local, self.ws
+        dist = self.torch.distributed if self.world > 1 else None
+        k.paths(self.prm, self.d_packed, seed, path_base + self.rank * n, n, self.d_terminal,
+                ws[_ffi.WS_PARTIALS], self.grid)
+        k.moments(K, ws[_ffi.WS_PARTIALS], self.grid, ws[_ffi.WS_MOMENTS])
+        if dist is not None:
+            dist.all_gather_into_tensor(self._gather, self.moments, group=self.group)
+            g = self._gather
+            self.moments[:, 0:3] = g[:, :, 0:3].sum(dim=0)
+            self.moments[:, 3] = g[:, :, 3].amin(dim=0)
+            self.moments[:, 4] = g[:, :, 4].amax(dim=0)
+        k.select_init(K, self.rank_lo, self.rank_hi, ws[_ffi.WS_STATE])
+        for p in range(3):
+            k.select_hist(K, self.d_terminal, n, p, ws[_ffi.WS_STATE], ws[_ffi.WS_HIST])
+            if dist is not None:
+                dist.all_reduce(self.hist, group=self.group)
+            k.select_scan(K, p, ws[_ffi.WS_HIST], ws[_ffi.WS_STATE])
+        k.quantile(self.prm, self.gamma, ws[_ffi.WS_STATE], ws[_ffi.WS_QUANT])
+        k.tail(self.prm, self.d_terminal, n, ws[_ffi.WS_QUANT], ws[_ffi.WS_TAIL_PARTIAL], ws[_ffi.WS_TAIL])
+        if dist is not None:
+            dist.all_reduce(self.tail, group=self.group)
+        k.stats(self.prm, ws[_ffi.WS_MOMENTS], ws[_ffi.WS_QUANT], ws[_ffi.WS_TAIL], ws[_ffi.WS_STATS])
+
+    def launch_paths_only(self, seed: int, path_base: int = 0):
+        """The dominant kernel alone (roofline timing)."""
+        n = self.n_local
+        self.k.paths(self.prm, self.d_packed, seed, path_base + self.rank * n, n, self.d_terminal,
+                     self.ws[_ffi.WS_PARTIALS], self.grid)
+
+    def stats(self) -> np.ndarray:
+        """Synchronise and fetch the [K] mcp_stats records of the last step()."""
+        nbytes = self.K * _ffi.STATS_DTYPE.itemsize
+        raw = self.ws[_ffi.WS_STATS].cpu().numpy().view(np.uint8)[:nbytes]
+        return raw.view(_ffi.STATS_DTYPE).copy()
+
+    def terminal(self) -> np.ndarray:
+        return self.d_terminal.cpu().numpy()

@@ -1,0 +1,139 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/mcport.h declares,
+and its host-only helpers behave (no kernel is launched here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from monte_carlo_portfolio_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mcport.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_ffi.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol(mcp_lib):
+    raw = ctypes.CDLL(_ffi.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(raw, name), name
+    assert mcp_lib.mcp_abi_version() == _ffi.MCP_ABI_VERSION
+    assert mcp_lib.mcp_device_count() >= 0
+
+
+def test_struct_layouts(mcp_lib):
+    assert ctypes.sizeof(_ffi.McpParams) == 48
+    assert ctypes.sizeof(_ffi.McpStats) == 104 == _ffi.STATS_DTYPE.itemsize
+    assert _ffi.MOMENTS_DTYPE.itemsize == 40
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_MOMENTS, 3, 0) == 3 * 40
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_STATS, 3, 0) == 3 * 104
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_HIST, 2, 0) == 2 * 2 * 2048 * 8
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_PARTIALS, 2, 7) == 2 * 7 * 40
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_STATE, 5, 0) == 5 * 2 * 16
+
+
+def test_pack_params_layout(mcp_lib):
+    rng = np.random.default_rng(0)
+    N, K = 6, 3
+    mu = rng.normal(size=N).astype(np.float32)
+    mu[2] = -0.0
+    L = rng.normal(size=(N, N)).astype(np.float32)      # upper part must be ignored
+    W = rng.normal(size=(K, N)).astype(np.float32)
+    p = _ffi.pack_params(mu, L, W)
+    n4 = 8
+    assert p.size == n4 + n4 * (n4 + 1) // 2 + 8 * n4 == mcp_lib.mcp_packed_len(N, K)
+    assert np.array_equal(p[:N], mu) and not np.signbit(p[2]) and np.all(p[N:n4] == 0)
+    Lp = p[n4:n4 + n4 * (n4 + 1) // 2]
+    for i in range(n4):
+        for j in range(i + 1):
+            want = L[i, j] if i < N else 0.0
+            assert Lp[i * (i + 1) // 2 + j] == want
+    Wp = p[n4 + n4 * (n4 + 1) // 2:].reshape(8, n4)
+    assert np.array_equal(Wp[:K, :N], W) and np.all(Wp[:K, N:] == 0) and np.all(Wp[K:] == 0)
+
+
+def test_pack_params_rejects_bad_shapes(mcp_lib):
+    assert mcp_lib.mcp_packed_len(0, 1) == 0 and mcp_lib.mcp_packed_len(65, 1) == 0 and mcp_lib.mcp_packed_len(4, 0) == 0
+    out = np.zeros(4, np.float32)
+    z = np.zeros(16, np.float32)
+    rc = mcp_lib.mcp_pack_params(4, 1, z[:4].copy(), z, z[:4].copy(), out, out.size)
+    assert rc == -1 and b"too small" in mcp_lib.mcp_last_error()
+
+
+@pytest.mark.parametrize("n", [1, 2, 13, 20, 21, 1000, 10_000, 1_000_000, 100_000_000, 999_999_937])
+@pytest.mark.parametrize("alpha", [0.95, 0.99, 0.5, 0.9])
+def test_percentile_rank_matches_numpy(n, alpha):
+    """lo/hi/gamma against numpy's own virtual index for q = (1-alpha)*100 (app.py:259)."""
+    from numpy.lib import _function_base_impl as fb
+    q = np.true_divide((1 - alpha) * 100, 100)
+    vi = fb._QuantileMethods["linear"]["get_virtual_index"](n, np.asarray(q))
+    lo, hi, g = _ffi.percentile_rank(n, alpha)
+    if vi >= n - 1:
+        assert lo == hi == n - 1
+    else:
+        assert lo == int(np.floor(vi)) and hi == lo + 1 and g == float(vi - np.floor(vi))
+
+
+def test_percentile_rank_reproduces_np_percentile():
+    rng = np.random.default_rng(5)
+    for alpha in (0.95, 0.99, 0.9, 0.5):
+        for n in (1, 2, 13, 21, 1000, 4097, 100_003, 1_000_000):
+            for rep in range(3 if n > 10_000 else 25):
+                x = rng.normal(size=n).astype(np.float32).astype(np.float64)
+                lo, hi, g = _ffi.percentile_rank(n, alpha)
+                xs = np.partition(x, [lo, hi])
+                a, b = xs[lo], xs[hi]
+                d = b - a
+                r = a + d * g if g < 0.5 else b - d * (1 - g)
+                assert r == np.percentile(x, (1 - alpha) * 100), (alpha, n)
+
+
+def test_key_transform_is_order_preserving(mcp_lib):
+    v = np.array([-np.inf, -3.5, -1e-30, -0.0, 0.0, 1e-38, 0.5, 1.0, 1.0000001, 7e9, np.inf], np.float32)
+    keys = [mcp_lib.mcp_float_to_key(float(x)) for x in v]
+    assert keys == sorted(keys) and len(set(keys[:3] + keys[5:])) == len(keys[:3] + keys[5:])
+    for x, k in zip(v, keys):
+        assert np.float32(mcp_lib.mcp_key_to_float(k)).tobytes() == np.float32(x).tobytes()
+
+
+def test_terminal_to_x(mcp_lib):
+    prm = _ffi.make_params(4, 10, 1, "simple", v0=0.1)
+    t = np.float32(0.1234)
+    assert mcp_lib.mcp_terminal_to_x(ctypes.byref(prm), t) == float(np.float64(t) / np.float64(np.float32(0.1)) - 1.0)
+    prm = _ffi.make_params(4, 10, 1, "log")
+    assert mcp_lib.mcp_terminal_to_x(ctypes.byref(prm), t) == pytest.approx(float(np.expm1(np.float64(t))), rel=1e-15)
+
+
+def test_argument_errors_are_reported_not_thrown(mcp_lib):
+    prm = _ffi.make_params(4, 10, 1)
+    prm.n_assets = 0
+    assert mcp_lib.mcp_paths_grid(ctypes.byref(prm), 100) == -1
+    assert b"n_assets" in mcp_lib.mcp_last_error()
+    prm = _ffi.make_params(4, 10, 1, alpha=0.95)
+    assert mcp_lib.mcp_paths_grid(ctypes.byref(prm), 1_000_000) == (1_000_000 + 255) // 256
+    assert mcp_lib.mcp_paths_grid(ctypes.byref(prm), 10 ** 9) == 8192
+    with pytest.raises(ValueError):
+        _ffi.make_params(4, 10, 1, compounding="weird")
+
+
+def test_product_fails_loudly_without_gpu(mcp_lib):
+    if mcp_lib.mcp_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from monte_carlo_portfolio_amd import simulate_paths
+    with pytest.raises(_ffi.McpError, match="no HIP device"):
+        simulate_paths(np.zeros(3), np.eye(3) * 1e-4, np.ones(3) / 3, n_paths=8)
+
+
+def test_not_positive_definite_is_value_error():
+    from monte_carlo_portfolio_amd.simulate import cholesky_factor
+    with pytest.raises(ValueError, match="positive definite"):
+        cholesky_factor(np.ones((3, 3)))

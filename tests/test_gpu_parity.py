@@ -1,0 +1,140 @@
+"""GPU parity tests proper: the HIP path, through the C ABI, against the CPU oracle.
+
+Bar (BASELINE.json north_star): fp32 results within 1e-6 relative; path counts exact.  The exact
+math mode does better than that: terminal values are required to be BIT-IDENTICAL to the oracle,
+VaR bit-identical to np.percentile on the oracle's values, fp64 moments within 1e-12.
+"""
+import numpy as np
+import pytest
+
+from monte_carlo_portfolio_amd import _ffi, simulate_paths, synthetic
+from monte_carlo_portfolio_amd.simulate import prepare_inputs
+from oracle import mc_oracle, ref_stats
+
+pytestmark = pytest.mark.gpu
+
+SEED = synthetic.BENCH_SEED
+
+
+def run_both(N, T, P, K=1, compounding="simple", v0=1.0, path_begin=0, native=False, alpha=0.95, rf=0.0, seed=SEED):
+    mu, cov = synthetic.synthetic_market(N)
+    W = synthetic.equal_weights(N) if K == 1 else synthetic.dirichlet_weights(N, K)
+    got = simulate_paths(mu, cov, W, n_steps=T, n_paths=P, seed=seed, v0=v0, compounding=compounding,
+                         rf=rf, alpha=alpha, store=True, path_begin=path_begin, native_math=native)
+    mu32, L, W32 = prepare_inputs(mu, cov, W)
+    ref = mc_oracle.simulate(mu32, L, W32, T, P, seed, path_begin=path_begin, v0=v0, compounding=compounding)
+    return ([got] if K == 1 else got), ref
+
+
+def assert_stats(got, ref_terminal, v0, compounding, alpha, rf, exact_quantile=True):
+    want = ref_stats.path_stats(ref_terminal, v0, compounding, alpha, rf)
+    assert got["n"] == want["n"] and got["n_tail"] == want["n_tail"]          # integer counts: exact
+    if exact_quantile:
+        assert got["var"] == want["var"]                                        # bit-exact np.percentile
+        assert got["min"] == want["min"] and got["max"] == want["max"]
+    else:
+        assert got["var"] == pytest.approx(want["var"], rel=1e-12)
+    for key in ("mean", "std", "sharpe", "cvar", "sum_tail"):
+        assert got[key] == pytest.approx(want[key], rel=1e-12, abs=1e-15), key
+
+
+@pytest.mark.parametrize("N,T,P", [(16, 252, 20_000), (3, 252, 10_000), (1, 30, 1000), (4, 7, 257),
+                                   (5, 17, 1000), (13, 40, 3000), (32, 25, 2000), (64, 20, 2000), (61, 9, 700)])
+def test_terminal_values_bit_exact(gpu_ctx, N, T, P):
+    got, ref = run_both(N, T, P)
+    V = got[0]["terminal"]
+    assert V.dtype == np.float32 and V.shape == (P,)
+    assert np.array_equal(V.view(np.uint32), ref[0].view(np.uint32))
+    assert_stats(got[0], ref[0], 1.0, "simple", 0.95, 0.0)
+
+
+def test_every_asset_count_bit_exact(gpu_ctx):
+    for N in range(1, 65):
+        got, ref = run_both(N, 6, 300)
+        assert np.array_equal(got[0]["terminal"].view(np.uint32), ref[0].view(np.uint32)), N
+
+
+@pytest.mark.parametrize("K", [2, 8, 9, 21])
+def test_multi_portfolio_common_random_numbers(gpu_ctx, K):
+    got, ref = run_both(16, 30, 5000, K=K, rf=0.001)
+    for k in range(K):
+        assert np.array_equal(got[k]["terminal"].view(np.uint32), ref[k].view(np.uint32)), k
+        assert_stats(got[k], ref[k], 1.0, "simple", 0.95, 0.001)
+    sharpe = np.array([g["sharpe"] for g in got])
+    want = np.array([ref_stats.path_stats(ref[k], rf=0.001)["sharpe"] for k in range(K)])
+    assert int(np.argmax(sharpe)) == int(np.argmax(want))        # argmax index: exact
+
+
+def test_log_compounding_and_v0(gpu_ctx):
+    got, ref = run_both(8, 50, 4000, compounding="log")
+    assert np.array_equal(got[0]["terminal"].view(np.uint32), ref[0].view(np.uint32))
+    assert_stats(got[0], ref[0], 1.0, "log", 0.95, 0.0, exact_quantile=False)
+    got, ref = run_both(8, 50, 4000, v0=10000.0, alpha=0.99, rf=0.01)
+    assert np.array_equal(got[0]["terminal"].view(np.uint32), ref[0].view(np.uint32))
+    assert_stats(got[0], ref[0], 10000.0, "simple", 0.99, 0.01)
+
+
+def test_path_offsets_partition_invariance(gpu_ctx):
+    """Counter-based RNG on the global path id: 4 shards == one run; also across the 2^32 boundary."""
+    mu, cov = synthetic.synthetic_market(16)
+    w = synthetic.equal_weights(16)
+    whole = simulate_paths(mu, cov, w, n_steps=20, n_paths=4096, seed=7, store=True)["terminal"]
+    parts = np.concatenate([simulate_paths(mu, cov, w, n_steps=20, n_paths=1024, seed=7, store=True,
+                                           path_begin=1024 * g)["terminal"] for g in range(4)])
+    assert np.array_equal(whole, parts)
+    got, ref = run_both(16, 12, 1000, path_begin=(1 << 32) - 500)
+    assert np.array_equal(got[0]["terminal"].view(np.uint32), ref[0].view(np.uint32))
+    got, ref = run_both(4, 12, 600, seed=0xFEDCBA9876543210)
+    assert np.array_equal(got[0]["terminal"].view(np.uint32), ref[0].view(np.uint32))
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 20, 21, 255, 256, 257, 513])
+def test_tiny_and_ragged_path_counts(gpu_ctx, P):
+    got, ref = run_both(16, 10, P)
+    assert np.array_equal(got[0]["terminal"].view(np.uint32), ref[0].view(np.uint32))
+    assert_stats(got[0], ref[0], 1.0, "simple", 0.95, 0.0)
+
+
+def test_zero_steps_and_degenerate_sigma(gpu_ctx):
+    mu, cov = synthetic.synthetic_market(4)
+    r = simulate_paths(mu, cov, np.ones(4) / 4, n_steps=0, n_paths=100, seed=1, store=True)
+    assert np.all(r["terminal"] == 1.0) and r["std"] == 0.0 and r["sharpe"] == 0.0 and r["var"] == 0.0
+    # zero covariance via an explicit zero factor: deterministic growth, all paths identical (ties)
+    r = simulate_paths(np.full(4, 1e-3), None, np.ones(4) / 4, n_steps=10, n_paths=1000, seed=1, store=True,
+                       chol=np.zeros((4, 4)))
+    assert np.all(r["terminal"] == r["terminal"][0]) and r["n_tail"] == 1000 and r["var"] == r["cvar"] == r["min"]
+
+
+def test_native_math_within_tolerance(gpu_ctx):
+    """Hardware log/sqrt/sin/cos variant: north_star's 1e-6 relative bar on the aggregates."""
+    got, ref = run_both(16, 252, 100_000, native=True)
+    V = got[0]["terminal"].astype(np.float64)
+    assert np.max(np.abs(V - ref[0]) / ref[0]) < 5e-6              # per path, loose
+    want = ref_stats.path_stats(ref[0])
+    assert got[0]["n"] == want["n"] and got[0]["n_tail"] == want["n_tail"]
+    for key in ("mean", "std", "sharpe", "var", "cvar"):
+        assert abs(got[0][key] - want[key]) <= 1e-6 * max(1.0, abs(want[key])) , key
+
+
+def test_config1_scale_properties(gpu_ctx):
+    """BASELINE config 1 at full size (16 assets, 1M paths, 252 steps): size-independent properties.
+    The first 50k paths are checked bit-exactly against the oracle; the rest through the statistics:
+    the lognormal-ish mean must match the analytic drift, n_tail = floor((n-1)q)+1, sortedness of the
+    order statistics, and shard-sum consistency of the moments."""
+    N, T, P = 16, 252, 1_000_000
+    mu, cov = synthetic.synthetic_market(N)
+    w = synthetic.equal_weights(N)
+    r = simulate_paths(mu, cov, w, n_steps=T, n_paths=P, seed=SEED, store=True)
+    V = r["terminal"]
+    mu32, L, W32 = prepare_inputs(mu, cov, w)
+    ref = mc_oracle.simulate(mu32, L, W32, T, 50_000, SEED)
+    assert np.array_equal(V[:50_000].view(np.uint32), ref[0].view(np.uint32))
+    x = V.astype(np.float64) - 1.0
+    assert r["n"] == P and r["n_tail"] == 50_000
+    assert r["var"] == np.percentile(x, (1 - 0.95) * 100)
+    assert r["x_lo"] <= r["var"] <= r["x_hi"] and r["min"] <= r["x_lo"] and r["x_hi"] <= r["max"]
+    assert r["mean"] == pytest.approx(x.mean(), rel=1e-12) and r["std"] == pytest.approx(x.std(ddof=1), rel=1e-12)
+    analytic = (1.0 + float(w @ mu)) ** T - 1.0                 # E[prod(1+rho_t)], iid steps
+    assert abs(r["mean"] - analytic) < 5 * r["std"] / np.sqrt(P)
+    halves = [simulate_paths(mu, cov, w, n_steps=T, n_paths=P // 2, seed=SEED, path_begin=g * (P // 2)) for g in range(2)]
+    assert halves[0]["mean"] * 0.5 + halves[1]["mean"] * 0.5 == pytest.approx(r["mean"], rel=1e-13)
