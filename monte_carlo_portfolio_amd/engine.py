@@ -110,7 +110,7 @@ class PathEngine:
         self.hist = self.ws[_ffi.WS_HIST]                                  # int64 counts [K][2][2048]
         self.tail = self.ws[_ffi.WS_TAIL].view(torch.float64).view(K, 2)
         if self.world > 1:
-            self._gather = torch.empty((self.world, K, 5), dtype=torch.float64, device=self.device)
+            self._gather = torch.empty((self.world * K, 5), dtype=torch.float64, device=self.device)
 
     def step(self, seed: int, path_base: int = 0):
         """Enqueue one full pass (paths -> statistics) on the current stream.  No host sync."""
@@ -121,7 +121,7 @@ class PathEngine:
         k.moments(K, ws[_ffi.WS_PARTIALS], self.grid, ws[_ffi.WS_MOMENTS])
         if dist is not None:
             dist.all_gather_into_tensor(self._gather, self.moments, group=self.group)
-            g = self._gather
+            g = self._gather.view(self.world, K, 5)
             self.moments[:, 0:3] = g[:, :, 0:3].sum(dim=0)
             self.moments[:, 3] = g[:, :, 3].amin(dim=0)
             self.moments[:, 4] = g[:, :, 4].amax(dim=0)

@@ -1,0 +1,138 @@
+"""Test double for monte_carlo_portfolio_amd.engine.HipKernels: the same step interface and the same
+buffer layouts, computed on CPU torch tensors with NumPy and the C oracle.
+
+TEST INFRASTRUCTURE ONLY.  It exists so the multi-rank choreography of PathEngine.step (shard
+offsets, moment merge, histogram all-reduce between select passes, tail all-reduce) runs on CPU with
+world_size 2 over gloo.  The product never imports this module.
+"""
+import ctypes
+
+import numpy as np
+
+from monte_carlo_portfolio_amd import _ffi
+from oracle import mc_oracle, ref_stats
+
+BINS = _ffi.MCP_SELECT_BINS
+SHAPE = {0: (21, 11, 32), 1: (10, 11, 21), 2: (0, 10, 10)}     # pass -> (shift, bits, prefix shift)
+
+
+def _keys(v):
+    b = v.view(np.uint32)
+    return np.where(b >> 31 != 0, ~b, b | np.uint32(0x80000000)).astype(np.uint32)
+
+
+def _key_to_float(k):
+    k = np.uint32(k)
+    b = np.uint32(k ^ np.uint32(0x80000000)) if (k >> 31) else np.uint32(~k)
+    return np.array([b], np.uint32).view(np.float32)[0]
+
+
+class FakeKernels:
+    device_type = "cpu"
+
+    def __init__(self, mu32, chol32, W32):
+        self.mu, self.L, self.W = mu32, chol32, W32
+
+    @staticmethod
+    def _np(t, dtype):
+        return t.numpy().view(dtype)
+
+    def paths_grid(self, prm, n):
+        return _ffi.check(_ffi.lib().mcp_paths_grid(ctypes.byref(prm), n))
+
+    def paths(self, prm, packed, seed, path_begin, n, terminal, partials, grid):
+        comp = "log" if prm.compounding == 1 else "simple"
+        term = mc_oracle.simulate(self.mu, self.L, self.W, prm.n_steps, n, seed, path_begin=path_begin,
+                                  v0=prm.v0, compounding=comp, n_threads=2)
+        terminal.numpy()[:, :n] = term
+        K = prm.n_portfolios
+        part = self._np(partials, np.float64).reshape(K, grid, 5)
+        part[:] = 0.0
+        part[:, :, 3] = np.inf
+        part[:, :, 4] = -np.inf
+        for k in range(K):       # spread the paths over the grid's blocks as the real kernel does (256 per tile)
+            x = ref_stats.terminal_to_x(term[k], prm.v0, comp)
+            for b in range(grid):
+                xb = x[b * 256:(b + 1) * 256] if grid * 256 >= n else x[b::grid]
+                if xb.size:
+                    part[k, b] = [xb.size, xb.sum(), (xb * xb).sum(), xb.min(), xb.max()]
+
+    def moments(self, K, partials, grid, moments):
+        part = self._np(partials, np.float64).reshape(K, grid, 5)
+        m = self._np(moments, np.float64).reshape(K, 5)
+        m[:, 0:3] = part[:, :, 0:3].sum(axis=1)
+        m[:, 3] = part[:, :, 3].min(axis=1)
+        m[:, 4] = part[:, :, 4].max(axis=1)
+
+    def select_init(self, K, lo, hi, state):
+        s = self._np(state, np.uint64).reshape(K, 2, 2)
+        s[:, :, 0] = 0
+        s[:, 0, 1] = lo
+        s[:, 1, 1] = hi
+
+    def select_hist(self, K, terminal, n, p, state, hist):
+        shift, bits, pshift = SHAPE[p]
+        s = self._np(state, np.uint64).reshape(K, 2, 2)
+        h = self._np(hist, np.int64).reshape(K, 2, BINS)
+        h[:] = 0
+        for k in range(K):
+            keys = _keys(terminal.numpy()[k, :n])
+            digit = (keys >> np.uint32(shift)) & np.uint32((1 << bits) - 1)
+            for w in range(2):
+                if p == 0:
+                    if w == 0:
+                        h[k, 0] = np.bincount(digit, minlength=BINS)
+                    continue
+                prefix = np.uint32(s[k, w, 0] & np.uint64(0xFFFFFFFF))
+                sel = (keys >> np.uint32(pshift)) == prefix
+                h[k, w] = np.bincount(digit[sel], minlength=BINS)
+
+    def select_scan(self, K, p, hist, state):
+        shift, bits, pshift = SHAPE[p]
+        s = self._np(state, np.uint64).reshape(K, 2, 2)
+        h = self._np(hist, np.int64).reshape(K, 2, BINS)
+        for k in range(K):
+            for w in range(2):
+                hh = h[k, 0 if p == 0 else w]
+                cum = np.cumsum(hh)
+                rank = int(s[k, w, 1])
+                d = int(np.searchsorted(cum, rank, side="right"))
+                before = int(cum[d - 1]) if d > 0 else 0
+                prefix = int(s[k, w, 0] & np.uint64(0xFFFFFFFF))
+                s[k, w, 0] = np.uint64(d if p == 0 else ((prefix << bits) | d) & 0xFFFFFFFF)
+                s[k, w, 1] = np.uint64(rank - before)
+
+    def quantile(self, prm, gamma, state, quant):
+        K = prm.n_portfolios
+        s = self._np(state, np.uint64).reshape(K, 2, 2)
+        q = self._np(quant, np.float64).reshape(K, 3)
+        comp = "log" if prm.compounding == 1 else "simple"
+        for k in range(K):
+            a, b = [ref_stats.terminal_to_x(np.array([_key_to_float(int(s[k, w, 0]) & 0xFFFFFFFF)], np.float32), prm.v0, comp)[0]
+                    for w in range(2)]
+            d = b - a
+            q[k] = [a, b, a + d * gamma if gamma < 0.5 else b - d * (1 - gamma)]
+
+    def tail(self, prm, terminal, n, quant, tail_partial, tail):
+        K = prm.n_portfolios
+        q = self._np(quant, np.float64).reshape(K, 3)
+        t = self._np(tail, np.float64).reshape(K, 2)
+        comp = "log" if prm.compounding == 1 else "simple"
+        for k in range(K):
+            x = ref_stats.terminal_to_x(terminal.numpy()[k, :n], prm.v0, comp)
+            m = x <= q[k, 2]
+            t[k] = [m.sum(), x[m].sum()]
+
+    def stats(self, prm, moments, quant, tail, stats):
+        K = prm.n_portfolios
+        m = self._np(moments, np.float64).reshape(K, 5)
+        q = self._np(quant, np.float64).reshape(K, 3)
+        t = self._np(tail, np.float64).reshape(K, 2)
+        out = stats.numpy().view(np.uint8)[:K * _ffi.STATS_DTYPE.itemsize].view(_ffi.STATS_DTYPE)
+        for k in range(K):
+            n, s1, s2 = m[k, 0], m[k, 1], m[k, 2]
+            mean = s1 / n
+            m2 = max(s2 - s1 * mean, 0.0)
+            std = np.sqrt(m2 / (n - 1)) if n > 1 else 0.0
+            out[k] = (int(n), int(t[k, 0]), mean, m2, std, (mean - prm.rf) / std if std > 0 else 0.0, q[k, 2],
+                      t[k, 1] / t[k, 0] if t[k, 0] > 0 else q[k, 2], m[k, 3], m[k, 4], t[k, 1], q[k, 0], q[k, 1])

@@ -1,0 +1,93 @@
+"""The N>1 path on CPU: world_size 2 over gloo.
+
+PathEngine.step's choreography is the product code under test; the kernels behind it are replaced by
+tests/fake_kernels.py (NumPy + oracle on CPU tensors, same buffer layouts).  Two ranks must produce
+exactly the statistics of one rank holding both shards, and both must equal the reference
+definitions (oracle/ref_stats.py) applied to the union of the paths.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from monte_carlo_portfolio_amd import synthetic
+from monte_carlo_portfolio_amd.engine import PathEngine
+from monte_carlo_portfolio_amd.simulate import prepare_inputs
+from fake_kernels import FakeKernels
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+N, T, n_local, K = {N}, {T}, {n_local}, {K}
+mu, cov = synthetic.synthetic_market(N)
+W = synthetic.dirichlet_weights(N, K) if K > 1 else synthetic.equal_weights(N)
+mu32, L, W32 = prepare_inputs(mu, cov, W)
+eng = PathEngine(mu32, L, W32, T, n_local, device="cpu", kernels=FakeKernels(mu32, L, W32), rf=0.002,
+                 group=dist.group.WORLD if world > 1 else None, world_size=world, rank=rank)
+eng.step(seed=77, path_base=1000)
+st = eng.stats()
+out = [{{k: (int(st[i][k]) if k in ("n", "n_tail") else float(st[i][k]).hex()) for k in st.dtype.names}} for i in range(K)]
+open({out!r} + str(rank), "w").write(json.dumps(out))
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_world(tmp_path, world, N, T, n_local, K):
+    out = str(tmp_path / f"res_w{world}_")
+    script = tmp_path / f"worker_w{world}.py"
+    script.write_text(WORKER.format(root=ROOT, N=N, T=T, n_local=n_local, K=K, out=out))
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, o.decode()[-3000:]
+    return [json.load(open(out + str(r))) for r in range(world)]
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_two_ranks_equal_one_rank_and_reference(tmp_path, K):
+    from monte_carlo_portfolio_amd import synthetic
+    from monte_carlo_portfolio_amd.simulate import prepare_inputs
+    from oracle import mc_oracle, ref_stats
+
+    N, T, n_local = 8, 12, 3001          # odd shard size: ragged last block
+    two = run_world(tmp_path, 2, N, T, n_local, K)
+    one = run_world(tmp_path, 1, N, T, 2 * n_local, K)
+    assert two[0] == two[1]                                  # every rank ends with the global statistics
+    mu, cov = synthetic.synthetic_market(N)
+    W = synthetic.dirichlet_weights(N, K) if K > 1 else synthetic.equal_weights(N)
+    mu32, L, W32 = prepare_inputs(mu, cov, W)
+    term = mc_oracle.simulate(mu32, L, W32, T, 2 * n_local, 77, path_begin=1000)
+    for k in range(K):
+        want = ref_stats.path_stats(term[k], rf=0.002)
+        a, b = two[0][k], one[0][k]
+        assert a["n"] == b["n"] == want["n"] == 2 * n_local
+        assert a["n_tail"] == b["n_tail"] == want["n_tail"]
+        for key in ("var", "x_lo", "x_hi", "min", "max"):     # order statistics: exact across partitions
+            assert a[key] == b[key], key
+        assert float.fromhex(a["var"]) == want["var"]
+        for key in ("mean", "std", "sharpe", "cvar"):         # fp64 sums: association differs across ranks
+            assert float.fromhex(a[key]) == pytest.approx(float.fromhex(b[key]), rel=1e-13)
+            assert float.fromhex(a[key]) == pytest.approx(want[key], rel=1e-12)
