@@ -106,7 +106,7 @@ int mcp_simulate(mcp_ctx *ctx, const mcp_params *prm,
  *      the buffer in place; a single-GPU host just runs the steps back to back. -------------------- */
 
 enum {
-    MCP_WS_PARTIALS = 0,   /* [K][grid] mcp_moments            (needs grid from mcp_paths_grid)      */
+    MCP_WS_PARTIALS = 0,   /* [K][256] mcp_moments: per-block partials of the moments pass          */
     MCP_WS_MOMENTS = 1,    /* [K] mcp_moments: all-reduce SUM on {n,sum,sumsq}, MIN on min, MAX on max */
     MCP_WS_STATE = 2,      /* [K][2] select state {u32 prefix, u32 pad, u64 rank}                   */
     MCP_WS_HIST = 3,       /* [K][2][MCP_SELECT_BINS] uint64: all-reduce SUM                        */
@@ -115,7 +115,7 @@ enum {
     MCP_WS_TAIL = 6,       /* [K] {double count, double sum}: all-reduce SUM                        */
     MCP_WS_STATS = 7       /* [K] mcp_stats                                                         */
 };
-size_t mcp_ws_bytes(int which, int n_portfolios, int grid);
+size_t mcp_ws_bytes(int which, int n_portfolios);
 
 /* Number of floats of the packed parameter block for (N, K). */
 size_t mcp_packed_len(int n_assets, int n_portfolios);
@@ -123,18 +123,15 @@ size_t mcp_packed_len(int n_assets, int n_portfolios);
 int mcp_pack_params(int n_assets, int n_portfolios, const float *mu, const float *chol, const float *W,
                     float *packed_out, size_t packed_len);
 
-/* Number of thread blocks mcp_launch_paths will use for n_paths on the current device (sizes the
- * partials buffer).  Returns <0 on error. */
-int mcp_paths_grid(const mcp_params *prm, uint64_t n_paths);
-
-/* Simulate paths [path_begin, path_begin+n_paths) of all K portfolios.  d_terminal: [K][terminal_stride]
- * floats (terminal_stride >= n_paths).  d_partials: MCP_WS_PARTIALS for `grid` = mcp_paths_grid(). */
+/* Simulate paths [path_begin, path_begin+n_paths) of all K portfolios and store the terminal values:
+ * d_terminal is [K][terminal_stride] floats (terminal_stride >= n_paths), 4 B per path and portfolio. */
 int mcp_launch_paths(const mcp_params *prm, const float *d_packed, uint64_t seed, uint64_t path_begin,
-                     uint64_t n_paths, float *d_terminal, uint64_t terminal_stride,
-                     void *d_partials, int grid, void *stream);
+                     uint64_t n_paths, float *d_terminal, uint64_t terminal_stride, void *stream);
 
-/* Reduce d_partials [K][grid] -> d_moments [K] in a fixed order (run-to-run deterministic). */
-int mcp_launch_moments(int n_portfolios, const void *d_partials, int grid, void *d_moments, void *stream);
+/* {n, sum x, sum x^2, min, max} of this device's n terminal values per portfolio -> d_moments [K]
+ * (fixed-order two-stage fp64 reduction: run-to-run deterministic). */
+int mcp_launch_moments(const mcp_params *prm, const float *d_terminal, uint64_t terminal_stride, uint64_t n,
+                       void *d_partials, void *d_moments, void *stream);
 
 /* np.percentile(x, (1-alpha)*100) bookkeeping (numpy 2.2 `_compute_virtual_index`/`_get_indexes`,
  * method 'linear'; the q of app.py:259): ranks of the two order statistics and the weight. */

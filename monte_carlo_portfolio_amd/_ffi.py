@@ -6,8 +6,10 @@ raises -- there is no NumPy/CPU fallback (a silent fallback would void every par
 from __future__ import annotations
 
 import ctypes
+import importlib.util
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -68,12 +70,11 @@ SIGNATURES = {
     "mcp_ctx_create": (_int, [_int, ctypes.POINTER(_vp)]),
     "mcp_ctx_destroy": (None, [_vp]),
     "mcp_simulate": (_int, [_vp, _PP, _f32p, _f32p, _f32p, _u64, _u64, _u64, _vp, _vp]),
-    "mcp_ws_bytes": (ctypes.c_size_t, [_int, _int, _int]),
+    "mcp_ws_bytes": (ctypes.c_size_t, [_int, _int]),
     "mcp_packed_len": (ctypes.c_size_t, [_int, _int]),
     "mcp_pack_params": (_int, [_int, _int, _f32p, _f32p, _f32p, _f32p, ctypes.c_size_t]),
-    "mcp_paths_grid": (_int, [_PP, _u64]),
-    "mcp_launch_paths": (_int, [_PP, _vp, _u64, _u64, _u64, _vp, _u64, _vp, _int, _vp]),
-    "mcp_launch_moments": (_int, [_int, _vp, _int, _vp, _vp]),
+    "mcp_launch_paths": (_int, [_PP, _vp, _u64, _u64, _u64, _vp, _u64, _vp]),
+    "mcp_launch_moments": (_int, [_PP, _vp, _u64, _u64, _vp, _vp, _vp]),
     "mcp_percentile_rank": (_int, [_u64, ctypes.c_double, ctypes.POINTER(_u64), ctypes.POINTER(_u64),
                                    ctypes.POINTER(ctypes.c_double)]),
     "mcp_launch_select_init": (_int, [_int, _u64, _u64, _vp, _vp]),
@@ -99,9 +100,27 @@ def build(force: bool = False, jobs: int = 8) -> str:
     return LIB_PATH
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7, the same as /opt/rocm's).  If libmcport.so pulled in the system copy first, a later
+    `import torch` would load a second runtime and find no GPU; so when torch is installed its copy is
+    loaded first and libmcport.so's DT_NEEDED binds to it by SONAME."""
+    if "torch" in sys.modules:
+        return                                  # torch already brought its runtime
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def lib() -> ctypes.CDLL:
     global _LIB
     if _LIB is None:
+        _preload_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `make -C {CSRC} -j8` (or __graft_entry__.build()). "

@@ -59,7 +59,11 @@ int check_params(const mcp_params* p) {
 int paths_per_thread(const mcp_params* p) {
   static const int env_ppt = [] {
     const char* e = getenv("MCP_PPT");
+#ifdef MCP_DEFAULT_PPT
+    return e ? atoi(e) : MCP_DEFAULT_PPT;
+#else
     return e ? atoi(e) : 1;
+#endif
   }();
   const int nb = (p->n_assets + 3) / 4;
   return (env_ppt == 2 && nb <= 4 && p->n_portfolios == 1) ? 2 : 1;
@@ -105,7 +109,7 @@ const char* mcp_last_error(void) { return g_err.c_str(); }
 size_t mcp_packed_len(int n_assets, int n_portfolios) {
   if (n_assets < 1 || n_assets > MCP_MAX_ASSETS || n_portfolios < 1) return 0;
   const size_t n4 = (size_t)n4_of(n_assets);
-  return n4 + n4 * (n4 + 1) / 2 + (size_t)kpad_of(n_portfolios) * n4;
+  return n4 + n4 * (n4 / 2 + 1) + (size_t)kpad_of(n_portfolios) * n4;
 }
 
 int mcp_pack_params(int n_assets, int n_portfolios, const float* mu, const float* chol, const float* W,
@@ -117,19 +121,21 @@ int mcp_pack_params(int n_assets, int n_portfolios, const float* mu, const float
   const int N = n_assets, n4 = n4_of(N);
   memset(out, 0, need * sizeof(float));
   for (int i = 0; i < N; i++) out[i] = mu[i] + 0.0f;   // -0 -> +0 (SPEC.md section 4)
+  // lower triangle in row pairs: pair m = rows (2m, 2m+1), columns j = 0..2m+1 interleaved as
+  // (L[2m][j], L[2m+1][j]); L[2m][2m+1] is a structural zero.  Offset of pair m: 2m(m+1).
   float* L = out + n4;
   for (int i = 0; i < N; i++)
-    for (int j = 0; j <= i; j++) L[i * (i + 1) / 2 + j] = chol[(size_t)i * N + j];
-  float* Wp = L + (size_t)n4 * (n4 + 1) / 2;
+    for (int j = 0; j <= i; j++) L[2 * (i / 2) * (i / 2 + 1) + 2 * j + (i & 1)] = chol[(size_t)i * N + j];
+  float* Wp = L + (size_t)n4 * (n4 / 2 + 1);
   for (int k = 0; k < n_portfolios; k++)
     for (int i = 0; i < N; i++) Wp[(size_t)k * n4 + i] = W[(size_t)k * N + i];
   return MCP_OK;
 }
 
-size_t mcp_ws_bytes(int which, int K, int grid) {
+size_t mcp_ws_bytes(int which, int K) {
   if (K < 1) return 0;
   switch (which) {
-    case MCP_WS_PARTIALS: return (size_t)K * (size_t)(grid > 0 ? grid : 0) * sizeof(mcp_moments);
+    case MCP_WS_PARTIALS: return (size_t)K * mcp::MOMENTS_GRID * sizeof(mcp_moments);
     case MCP_WS_MOMENTS: return (size_t)K * sizeof(mcp_moments);
     case MCP_WS_STATE: return (size_t)K * 2 * sizeof(mcp::SelectState);
     case MCP_WS_HIST: return (size_t)K * 2 * MCP_SELECT_BINS * sizeof(unsigned long long);
@@ -141,8 +147,7 @@ size_t mcp_ws_bytes(int which, int K, int grid) {
   }
 }
 
-int mcp_paths_grid(const mcp_params* prm, uint64_t n_paths) {
-  if (int rc = check_params(prm)) return rc;
+static int paths_grid(const mcp_params* prm, uint64_t n_paths) {
   const uint64_t tile = (uint64_t)mcp::PATH_BLOCK * paths_per_thread(prm);
   uint64_t tiles = (n_paths + tile - 1) / tile;
   if (tiles < 1) tiles = 1;
@@ -150,13 +155,13 @@ int mcp_paths_grid(const mcp_params* prm, uint64_t n_paths) {
 }
 
 int mcp_launch_paths(const mcp_params* prm, const float* d_packed, uint64_t seed, uint64_t path_begin,
-                     uint64_t n_paths, float* d_terminal, uint64_t stride, void* d_partials, int grid,
-                     void* stream) {
+                     uint64_t n_paths, float* d_terminal, uint64_t stride, void* stream) {
   if (int rc = check_params(prm)) return rc;
-  if (!d_packed || !d_terminal || !d_partials) return fail(MCP_E_ARG, "NULL device pointer");
+  if (!d_packed || !d_terminal) return fail(MCP_E_ARG, "NULL device pointer");
+  if (n_paths < 1) return fail(MCP_E_ARG, "n_paths must be >= 1");
   if (stride < n_paths) return fail(MCP_E_ARG, "terminal_stride %llu < n_paths %llu",
                                     (unsigned long long)stride, (unsigned long long)n_paths);
-  if (grid != mcp_paths_grid(prm, n_paths)) return fail(MCP_E_ARG, "grid %d != mcp_paths_grid()", grid);
+  const int grid = paths_grid(prm, n_paths);
   if ((uint64_t)prm->n_steps * (uint64_t)((prm->n_assets + 3) / 4) > 0xFFFFFFFFull)
     return fail(MCP_E_UNSUPPORTED, "n_steps * ceil(N/4) exceeds the 32-bit Philox block counter");
   const int nb = (prm->n_assets + 3) / 4;
@@ -169,7 +174,6 @@ int mcp_launch_paths(const mcp_params* prm, const float* d_packed, uint64_t seed
   mcp::PathArgs a;
   a.packed = d_packed;
   a.terminal = d_terminal;
-  a.partials = (mcp_moments*)d_partials;
   a.seed = seed;
   a.path_begin = path_begin;
   a.n_paths = n_paths;
@@ -186,9 +190,12 @@ int mcp_launch_paths(const mcp_params* prm, const float* d_packed, uint64_t seed
   return MCP_OK;
 }
 
-int mcp_launch_moments(int K, const void* d_partials, int grid, void* d_moments, void* stream) {
-  if (K < 1 || grid < 1 || !d_partials || !d_moments) return fail(MCP_E_ARG, "bad argument");
-  HIP_TRY(mcp::launch_moments(K, (const mcp_moments*)d_partials, grid, (mcp_moments*)d_moments, (hipStream_t)stream));
+int mcp_launch_moments(const mcp_params* prm, const float* d_terminal, uint64_t stride, uint64_t n,
+                       void* d_partials, void* d_moments, void* stream) {
+  if (int rc = check_params(prm)) return rc;
+  if (!d_terminal || !d_partials || !d_moments || stride < n) return fail(MCP_E_ARG, "bad argument");
+  HIP_TRY(mcp::launch_moments(*prm, prm->n_portfolios, d_terminal, stride, n, (mcp_moments*)d_partials,
+                              (mcp_moments*)d_moments, (hipStream_t)stream));
   return MCP_OK;
 }
 
@@ -325,13 +332,11 @@ int mcp_simulate(mcp_ctx* c, const mcp_params* prm, const float* mu, const float
   std::lock_guard<std::mutex> lock(c->mu);
   HIP_TRY(hipSetDevice(c->device));
   const int K = prm->n_portfolios;
-  const int grid = mcp_paths_grid(prm, n_paths);
-  if (grid < 0) return grid;
   const size_t plen = mcp_packed_len(prm->n_assets, K);
 
   int rc;
   for (int w = 0; w < 8; w++)
-    if ((rc = grow_dev(&c->d[w], &c->cap[w], mcp_ws_bytes(w, K, grid)))) return rc;
+    if ((rc = grow_dev(&c->d[w], &c->cap[w], mcp_ws_bytes(w, K)))) return rc;
   if ((rc = grow_dev((void**)&c->d_packed, &c->packed_cap, plen * sizeof(float)))) return rc;
   if ((rc = grow_dev((void**)&c->d_terminal, &c->terminal_cap, (size_t)K * n_paths * sizeof(float)))) return rc;
   if ((rc = grow_host((void**)&c->h_packed, &c->h_packed_cap, plen * sizeof(float)))) return rc;
@@ -345,9 +350,8 @@ int mcp_simulate(mcp_ctx* c, const mcp_params* prm, const float* mu, const float
   double gamma;
   if ((rc = mcp_percentile_rank(n_paths, prm->alpha, &lo, &hi, &gamma))) return rc;
 
-  if ((rc = mcp_launch_paths(prm, c->d_packed, seed, path_begin, n_paths, c->d_terminal, n_paths,
-                             c->d[MCP_WS_PARTIALS], grid, s))) return rc;
-  if ((rc = mcp_launch_moments(K, c->d[MCP_WS_PARTIALS], grid, c->d[MCP_WS_MOMENTS], s))) return rc;
+  if ((rc = mcp_launch_paths(prm, c->d_packed, seed, path_begin, n_paths, c->d_terminal, n_paths, s))) return rc;
+  if ((rc = mcp_launch_moments(prm, c->d_terminal, n_paths, n_paths, c->d[MCP_WS_PARTIALS], c->d[MCP_WS_MOMENTS], s))) return rc;
   if ((rc = mcp_launch_select_init(K, lo, hi, c->d[MCP_WS_STATE], s))) return rc;
   for (int pass = 0; pass < 3; pass++) {
     if ((rc = mcp_launch_select_hist(K, c->d_terminal, n_paths, n_paths, pass, c->d[MCP_WS_STATE], c->d[MCP_WS_HIST], s))) return rc;

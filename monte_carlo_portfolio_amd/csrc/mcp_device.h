@@ -18,22 +18,43 @@ constexpr uint32_t PHILOX_M1 = 0xCD9E8D57u;
 constexpr uint32_t PHILOX_W0 = 0x9E3779B9u;
 constexpr uint32_t PHILOX_W1 = 0xBB67AE85u;
 
-// One Philox4x32-10 block.  The key schedule is wave-uniform (it depends on the seed only) and
-// stays on the scalar unit; each round is two v_mad_u64_u32 and two v_xor3_b32 per lane.
+#ifndef MCP_EXP_BITOP3
+#define MCP_EXP_BITOP3 1
+#endif
+
+// a ^ b ^ c in one VALU instruction (v_bitop3_b32, truth table 0x96).
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if MCP_EXP_BITOP3
+  return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+  return a ^ b ^ c;
+#endif
+}
+
+// Round keys of Philox4x32-10: key_r = key_0 + r*(W0, W1).  They depend on the seed only.
+struct PhiloxKeys {
+  uint32_t k0[10], k1[10];
+};
+__device__ __forceinline__ PhiloxKeys philox_keys(uint32_t k0, uint32_t k1) {
+  PhiloxKeys ks;
+#pragma unroll
+  for (int r = 0; r < 10; r++) { ks.k0[r] = k0 + (uint32_t)r * PHILOX_W0; ks.k1[r] = k1 + (uint32_t)r * PHILOX_W1; }
+  return ks;
+}
+
+// One Philox4x32-10 block: per round two v_mad_u64_u32 and two three-input xors per lane.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                              uint32_t k0, uint32_t k1, uint32_t (&x)[4]) {
+                                              const PhiloxKeys& ks, uint32_t (&x)[4]) {
 #pragma unroll
   for (int r = 0; r < 10; r++) {
     const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
     const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, ks.k0[r]);
+    const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, ks.k1[r]);
     c1 = (uint32_t)p1;
     c3 = (uint32_t)p0;
     c0 = n0;
     c2 = n2;
-    k0 += PHILOX_W0;
-    k1 += PHILOX_W1;
   }
   x[0] = c0; x[1] = c1; x[2] = c2; x[3] = c3;
 }

@@ -2,7 +2,7 @@
 //
 //   mc_paths_kernel   N1+N2 of SURVEY.md section 8(a): Philox4x32-10 -> Box-Muller -> r = mu + L z ->
 //                     rho = w.r -> V <- V(1+rho) over T steps, entirely in registers; writes V_T
-//                     (4 B/path, coalesced) and per-block fp64 moment partials.
+//                     (4 B/path, coalesced).  All statistics are separate streaming passes over V_T.
 //                     Conventions inherited from the reference: fixed-weight portfolio return
 //                     `returns_df @ ws` (app.py:710), compounding prod(1+r) (app.py:249, app.py:253).
 //
@@ -17,12 +17,17 @@
 #include "../../include/mcport.h"
 #include "mcp_device.h"
 
+#ifndef MCP_EXP_VKEYS
+#define MCP_EXP_VKEYS 1
+#endif
+
 namespace mcp {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 struct PathArgs {
-  const float* __restrict__ packed;   // [mu N4][L packed lower N4(N4+1)/2][W K*N4]
+  const float* __restrict__ packed;   // [mu N4][L row pairs N4(N4/2+1)][W Kpad*N4]  (mcp_pack_params)
   float* __restrict__ terminal;       // [K][stride]
-  mcp_moments* __restrict__ partials; // [K][gridDim.x]
   uint64_t seed, path_begin, n_paths, stride;
   int32_t n_steps, n_portfolios, k_begin, compounding;
   float v0;
@@ -59,17 +64,16 @@ __global__ void __launch_bounds__(PATH_BLOCK) mc_paths_kernel(const PathArgs a) 
   typedef const __attribute__((address_space(4))) float* cfloat_p;
   cfloat_p mu = (cfloat_p)a.packed;
   cfloat_p Lp = mu + N4;
-  cfloat_p Wk = mu + N4 + N4 * (N4 + 1) / 2 + (size_t)a.k_begin * N4;
+  cfloat_p Wk = mu + N4 + N4 * (N4 / 2 + 1) + (size_t)a.k_begin * N4;
   const int kt = min(KT, a.n_portfolios - a.k_begin);   // live portfolios in this pass (uniform)
-  const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+  PhiloxKeys ks = philox_keys((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+#if MCP_EXP_VKEYS
+  // pin the 20 round keys in VGPRs: an SGPR operand halves the issue rate of the xor (profiles/r01_valu_rates.txt)
+#pragma unroll
+  for (int r = 0; r < 10; r++) { asm volatile("" : "+v"(ks.k0[r])); asm volatile("" : "+v"(ks.k1[r])); }
+#endif
   const int T = a.n_steps;
   const bool logc = a.compounding == MCP_COMPOUND_LOG;
-  const double v0d = (double)a.v0;
-
-  double s1[KT], s2[KT], mn[KT], mx[KT];
-  double cnt = 0.0;
-#pragma unroll
-  for (int k = 0; k < KT; k++) { s1[k] = 0.0; s2[k] = 0.0; mn[k] = __builtin_inf(); mx[k] = -__builtin_inf(); }
 
   const uint64_t tile = (uint64_t)PATH_BLOCK * PPT;
   const uint64_t n_tiles = (a.n_paths + tile - 1) / tile;
@@ -98,7 +102,7 @@ __global__ void __launch_bounds__(PATH_BLOCK) mc_paths_kernel(const PathArgs a) 
 #pragma unroll
         for (int e = 0; e < PPT; e++) {
           uint32_t x[4];
-          philox4x32_10(blk, 0u, plo[e], phi[e], k0, k1, x);
+          philox4x32_10(blk, 0u, plo[e], phi[e], ks, x);
           box_muller<NATIVE>(x[0], x[1], z[e][0 * NB + q], z[e][1 * NB + q]);
           box_muller<NATIVE>(x[2], x[3], z[e][2 * NB + q], z[e][3 * NB + q]);
         }
@@ -109,23 +113,29 @@ __global__ void __launch_bounds__(PATH_BLOCK) mc_paths_kernel(const PathArgs a) 
       for (int e = 0; e < PPT; e++)
 #pragma unroll
         for (int k = 0; k < KT; k++) rho[e][k] = 0.0f;
+      // Rows are processed in pairs (2m, 2m+1): one v_pk_fma_f32 per column does both rows, its L operand
+      // an SGPR pair straight from the row-pair-interleaved parameter block, z_j broadcast by op_sel.
 #pragma unroll
-      for (int i = 0; i < N4; i++) {
-        float acc[PPT];
-        const float mui = mu[i];
+      for (int m = 0; m < N4 / 2; m++) {
+        f32x2 acc[PPT];
+        const f32x2 mu2 = {mu[2 * m], mu[2 * m + 1]};
 #pragma unroll
-        for (int e = 0; e < PPT; e++) acc[e] = mui;
+        for (int e = 0; e < PPT; e++) acc[e] = mu2;
 #pragma unroll
-        for (int j = 0; j <= i; j++) {
-          const float lij = Lp[i * (i + 1) / 2 + j];
+        for (int j = 0; j <= 2 * m + 1; j++) {
+          const f32x2 l2 = {Lp[2 * m * (m + 1) + 2 * j], Lp[2 * m * (m + 1) + 2 * j + 1]};   // (L[2m][j], L[2m+1][j])
 #pragma unroll
-          for (int e = 0; e < PPT; e++) acc[e] = fma32(lij, z[e][j], acc[e]);
+          for (int e = 0; e < PPT; e++) acc[e] = __builtin_elementwise_fma(l2, (f32x2){z[e][j], z[e][j]}, acc[e]);
         }
 #pragma unroll
-        for (int k = 0; k < KT; k++) {
-          const float wki = Wk[k * N4 + i];              // rows >= kt are zero-padded by pack_params
+        for (int h = 0; h < 2; h++) {
+          const int i = 2 * m + h;
 #pragma unroll
-          for (int e = 0; e < PPT; e++) rho[e][k] = fma32(wki, acc[e], rho[e][k]);
+          for (int k = 0; k < KT; k++) {
+            const float wki = Wk[k * N4 + i];              // rows >= kt are zero-padded by pack_params
+#pragma unroll
+            for (int e = 0; e < PPT; e++) rho[e][k] = fma32(wki, h ? acc[e].y : acc[e].x, rho[e][k]);
+          }
         }
       }
 #pragma unroll
@@ -138,41 +148,13 @@ __global__ void __launch_bounds__(PATH_BLOCK) mc_paths_kernel(const PathArgs a) 
 #pragma unroll
     for (int e = 0; e < PPT; e++) {
       if (live[e]) {
-        cnt += 1.0;
 #pragma unroll
-        for (int k = 0; k < KT; k++) {
-          if (k < kt) {
-            a.terminal[(size_t)(a.k_begin + k) * a.stride + p[e]] = V[e][k];
-            const double x = terminal_to_x(V[e][k], v0d, a.compounding);
-            s1[k] += x; s2[k] += x * x; mn[k] = fmin(mn[k], x); mx[k] = fmax(mx[k], x);
-          }
-        }
+        for (int k = 0; k < KT; k++)
+          if (k < kt) a.terminal[(size_t)(a.k_begin + k) * a.stride + p[e]] = V[e][k];
       }
     }
   }
 
-  // block reduction of the moment partials: wave shuffles, then 4 waves through LDS
-  __shared__ double red[PATH_BLOCK / 64][5];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const double c_w = wave_sum(cnt);
-  for (int k = 0; k < kt; k++) {
-    double v1 = s1[0], v2 = s2[0], vmn = mn[0], vmx = mx[0];
-#pragma unroll
-    for (int kk = 1; kk < KT; kk++)
-      if (kk == k) { v1 = s1[kk]; v2 = s2[kk]; vmn = mn[kk]; vmx = mx[kk]; }
-    v1 = wave_sum(v1); v2 = wave_sum(v2); vmn = wave_min(vmn); vmx = wave_max(vmx);
-    __syncthreads();
-    if (lane == 0) { red[wv][0] = c_w; red[wv][1] = v1; red[wv][2] = v2; red[wv][3] = vmn; red[wv][4] = vmx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      mcp_moments m = {red[0][0], red[0][1], red[0][2], red[0][3], red[0][4]};
-      for (int w = 1; w < PATH_BLOCK / 64; w++) {
-        m.n += red[w][0]; m.sum += red[w][1]; m.sumsq += red[w][2];
-        m.min = fmin(m.min, red[w][3]); m.max = fmax(m.max, red[w][4]);
-      }
-      a.partials[(size_t)(a.k_begin + k) * gridDim.x + blockIdx.x] = m;
-    }
-  }
 }
 
 }  // namespace mcp

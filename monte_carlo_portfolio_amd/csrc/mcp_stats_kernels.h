@@ -18,6 +18,7 @@ struct Quantile {
 };
 
 constexpr int TAIL_GRID = 256;
+constexpr int MOMENTS_GRID = 256;
 
 struct PathArgs;
 
@@ -32,7 +33,8 @@ MCP_DECL_NB(1) MCP_DECL_NB(2) MCP_DECL_NB(3) MCP_DECL_NB(4) MCP_DECL_NB(5) MCP_D
 MCP_DECL_NB(9) MCP_DECL_NB(10) MCP_DECL_NB(11) MCP_DECL_NB(12) MCP_DECL_NB(13) MCP_DECL_NB(14) MCP_DECL_NB(15) MCP_DECL_NB(16)
 #undef MCP_DECL_NB
 
-hipError_t launch_moments(int K, const mcp_moments* partials, int grid, mcp_moments* out, hipStream_t s);
+hipError_t launch_moments(const mcp_params& prm, int K, const float* terminal, uint64_t stride, uint64_t n,
+                          mcp_moments* partials, mcp_moments* out, hipStream_t s);
 hipError_t launch_select_init(int K, uint64_t rank_lo, uint64_t rank_hi, SelectState* state, hipStream_t s);
 hipError_t launch_select_hist(int K, const float* terminal, uint64_t stride, uint64_t n, int pass,
                               const SelectState* state, unsigned long long* hist, hipStream_t s);

@@ -1,6 +1,6 @@
 // mcp_stats_kernels.hip -- reductions behind the path kernel (gfx950).
 //
-//   moments_kernel    deterministic fixed-order reduction of the per-block partials.
+//   moments_*         n, sum x, sum x^2, min, max of x over V_T (fp64, deterministic two-stage reduction).
 //   select_*          exact order statistics by 3-pass radix select on the float bit pattern; they
 //                     feed np.percentile's linear interpolation (app.py:258-259, numpy 2.2 _lerp).
 //   tail_*            count / sum of x <= VaR (app.py:261-263).
@@ -10,6 +10,33 @@
 #include "mcp_stats_kernels.h"
 
 namespace mcp {
+
+// Moments of x over V_T: partial[k][b] = {n, sum x, sum x^2, min, max} of a grid-stride slice (fp64), then
+// a fixed-order sum of the MOMENTS_GRID partials -> run-to-run deterministic.  grid = (MOMENTS_GRID, K).
+__global__ void __launch_bounds__(256) moments_partial_kernel(const mcp_params prm, const float* __restrict__ terminal,
+                                                              uint64_t stride, uint64_t n, mcp_moments* __restrict__ partial) {
+  const int k = blockIdx.y;
+  const double v0d = (double)(float)prm.v0;
+  const float* __restrict__ src = terminal + (size_t)k * stride;
+  double c = 0.0, s1 = 0.0, s2 = 0.0, mn = __builtin_inf(), mx = -__builtin_inf();
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const double x = terminal_to_x(src[i], v0d, prm.compounding);
+    c += 1.0; s1 += x; s2 += x * x; mn = fmin(mn, x); mx = fmax(mx, x);
+  }
+  __shared__ double red[4][5];
+  c = wave_sum(c); s1 = wave_sum(s1); s2 = wave_sum(s2); mn = wave_min(mn); mx = wave_max(mx);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[wv][0] = c; red[wv][1] = s1; red[wv][2] = s2; red[wv][3] = mn; red[wv][4] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mcp_moments m = {red[0][0], red[0][1], red[0][2], red[0][3], red[0][4]};
+    for (int w = 1; w < 4; w++) {
+      m.n += red[w][0]; m.sum += red[w][1]; m.sumsq += red[w][2];
+      m.min = fmin(m.min, red[w][3]); m.max = fmax(m.max, red[w][4]);
+    }
+    partial[(size_t)k * gridDim.x + blockIdx.x] = m;
+  }
+}
 
 // partials [K][grid] -> moments [K]; one block per portfolio, fixed summation order.
 __global__ void __launch_bounds__(256) moments_kernel(const mcp_moments* __restrict__ partials, int grid,
@@ -199,8 +226,12 @@ __global__ void select_init_kernel(int K, uint64_t rank_lo, uint64_t rank_hi, Se
 }
 
 // ---- launch wrappers (enqueue only) -------------------------------------------------------------
-hipError_t launch_moments(int K, const mcp_moments* partials, int grid, mcp_moments* out, hipStream_t s) {
-  moments_kernel<<<K, 256, 0, s>>>(partials, grid, out);
+hipError_t launch_moments(const mcp_params& prm, int K, const float* terminal, uint64_t stride, uint64_t n,
+                          mcp_moments* partials, mcp_moments* out, hipStream_t s) {
+  moments_partial_kernel<<<dim3(MOMENTS_GRID, (unsigned)K), 256, 0, s>>>(prm, terminal, stride, n, partials);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  moments_kernel<<<K, 256, 0, s>>>(partials, MOMENTS_GRID, out);
   return hipGetLastError();
 }
 

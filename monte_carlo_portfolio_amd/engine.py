@@ -44,16 +44,13 @@ class HipKernels:
     def _p(t):
         return ctypes.c_void_p(t.data_ptr())
 
-    def paths_grid(self, prm, n):
-        return _ffi.check(self.lib.mcp_paths_grid(ctypes.byref(prm), n))
-
-    def paths(self, prm, packed, seed, path_begin, n, terminal, partials, grid):
+    def paths(self, prm, packed, seed, path_begin, n, terminal):
         _ffi.check(self.lib.mcp_launch_paths(ctypes.byref(prm), self._p(packed), seed, path_begin, n,
-                                             self._p(terminal), terminal.shape[1], self._p(partials), grid,
-                                             self._stream()))
+                                             self._p(terminal), terminal.shape[1], self._stream()))
 
-    def moments(self, K, partials, grid, moments):
-        _ffi.check(self.lib.mcp_launch_moments(K, self._p(partials), grid, self._p(moments), self._stream()))
+    def moments(self, prm, terminal, n, partials, moments):
+        _ffi.check(self.lib.mcp_launch_moments(ctypes.byref(prm), self._p(terminal), terminal.shape[1], n,
+                                               self._p(partials), self._p(moments), self._stream()))
 
     def select_init(self, K, lo, hi, state):
         _ffi.check(self.lib.mcp_launch_select_init(K, lo, hi, self._p(state), self._stream()))
@@ -94,7 +91,6 @@ class PathEngine:
         K = W32.shape[0]
         self.K = K
         self.prm = _ffi.make_params(mu32.shape[0], n_steps, K, compounding, v0, alpha, rf, native_math)
-        self.grid = self.k.paths_grid(self.prm, self.n_local)
         self.rank_lo, self.rank_hi, self.gamma = _ffi.percentile_rank(self.n_total, alpha)
 
         lib = _ffi.lib()
@@ -103,7 +99,7 @@ class PathEngine:
         self.d_terminal = torch.empty((K, self.n_local), dtype=torch.float32, device=self.device)
         self.ws = {}
         for which in range(8):
-            nbytes = lib.mcp_ws_bytes(which, K, self.grid)
+            nbytes = lib.mcp_ws_bytes(which, K)
             self.ws[which] = torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=self.device)
         # typed views for the collectives
         self.moments = self.ws[_ffi.WS_MOMENTS].view(torch.float64).view(K, 5)
@@ -116,9 +112,8 @@ class PathEngine:
         """Enqueue one full pass (paths -> statistics) on the current stream.  No host sync."""
         k, K, n, ws = self.k, self.K, self.n_local, self.ws
         dist = self.torch.distributed if self.world > 1 else None
-        k.paths(self.prm, self.d_packed, seed, path_base + self.rank * n, n, self.d_terminal,
-                ws[_ffi.WS_PARTIALS], self.grid)
-        k.moments(K, ws[_ffi.WS_PARTIALS], self.grid, ws[_ffi.WS_MOMENTS])
+        k.paths(self.prm, self.d_packed, seed, path_base + self.rank * n, n, self.d_terminal)
+        k.moments(self.prm, self.d_terminal, n, ws[_ffi.WS_PARTIALS], ws[_ffi.WS_MOMENTS])
         if dist is not None:
             dist.all_gather_into_tensor(self._gather, self.moments, group=self.group)
             g = self._gather.view(self.world, K, 5)
@@ -140,8 +135,7 @@ class PathEngine:
     def launch_paths_only(self, seed: int, path_base: int = 0):
         """The dominant kernel alone (roofline timing)."""
         n = self.n_local
-        self.k.paths(self.prm, self.d_packed, seed, path_base + self.rank * n, n, self.d_terminal,
-                     self.ws[_ffi.WS_PARTIALS], self.grid)
+        self.k.paths(self.prm, self.d_packed, seed, path_base + self.rank * n, n, self.d_terminal)
 
     def stats(self) -> np.ndarray:
         """Synchronise and fetch the [K] mcp_stats records of the last step()."""

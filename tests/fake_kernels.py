@@ -37,32 +37,18 @@ class FakeKernels:
     def _np(t, dtype):
         return t.numpy().view(dtype)
 
-    def paths_grid(self, prm, n):
-        return _ffi.check(_ffi.lib().mcp_paths_grid(ctypes.byref(prm), n))
-
-    def paths(self, prm, packed, seed, path_begin, n, terminal, partials, grid):
+    def paths(self, prm, packed, seed, path_begin, n, terminal):
         comp = "log" if prm.compounding == 1 else "simple"
-        term = mc_oracle.simulate(self.mu, self.L, self.W, prm.n_steps, n, seed, path_begin=path_begin,
-                                  v0=prm.v0, compounding=comp, n_threads=2)
-        terminal.numpy()[:, :n] = term
-        K = prm.n_portfolios
-        part = self._np(partials, np.float64).reshape(K, grid, 5)
-        part[:] = 0.0
-        part[:, :, 3] = np.inf
-        part[:, :, 4] = -np.inf
-        for k in range(K):       # spread the paths over the grid's blocks as the real kernel does (256 per tile)
-            x = ref_stats.terminal_to_x(term[k], prm.v0, comp)
-            for b in range(grid):
-                xb = x[b * 256:(b + 1) * 256] if grid * 256 >= n else x[b::grid]
-                if xb.size:
-                    part[k, b] = [xb.size, xb.sum(), (xb * xb).sum(), xb.min(), xb.max()]
+        terminal.numpy()[:, :n] = mc_oracle.simulate(self.mu, self.L, self.W, prm.n_steps, n, seed, path_begin=path_begin,
+                                                     v0=prm.v0, compounding=comp, n_threads=2)
 
-    def moments(self, K, partials, grid, moments):
-        part = self._np(partials, np.float64).reshape(K, grid, 5)
+    def moments(self, prm, terminal, n, partials, moments):
+        K = prm.n_portfolios
+        comp = "log" if prm.compounding == 1 else "simple"
         m = self._np(moments, np.float64).reshape(K, 5)
-        m[:, 0:3] = part[:, :, 0:3].sum(axis=1)
-        m[:, 3] = part[:, :, 3].min(axis=1)
-        m[:, 4] = part[:, :, 4].max(axis=1)
+        for k in range(K):
+            x = ref_stats.terminal_to_x(terminal.numpy()[k, :n], prm.v0, comp)
+            m[k] = [x.size, x.sum(), (x * x).sum(), x.min(), x.max()]
 
     def select_init(self, K, lo, hi, state):
         s = self._np(state, np.uint64).reshape(K, 2, 2)

@@ -34,11 +34,11 @@ def test_struct_layouts(mcp_lib):
     assert ctypes.sizeof(_ffi.McpParams) == 48
     assert ctypes.sizeof(_ffi.McpStats) == 104 == _ffi.STATS_DTYPE.itemsize
     assert _ffi.MOMENTS_DTYPE.itemsize == 40
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_MOMENTS, 3, 0) == 3 * 40
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_STATS, 3, 0) == 3 * 104
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_HIST, 2, 0) == 2 * 2 * 2048 * 8
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_PARTIALS, 2, 7) == 2 * 7 * 40
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_STATE, 5, 0) == 5 * 2 * 16
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_MOMENTS, 3) == 3 * 40
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_STATS, 3) == 3 * 104
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_HIST, 2) == 2 * 2 * 2048 * 8
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_PARTIALS, 2) == 2 * 256 * 40
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_STATE, 5) == 5 * 2 * 16
 
 
 def test_pack_params_layout(mcp_lib):
@@ -50,14 +50,16 @@ def test_pack_params_layout(mcp_lib):
     W = rng.normal(size=(K, N)).astype(np.float32)
     p = _ffi.pack_params(mu, L, W)
     n4 = 8
-    assert p.size == n4 + n4 * (n4 + 1) // 2 + 8 * n4 == mcp_lib.mcp_packed_len(N, K)
+    assert p.size == n4 + n4 * (n4 // 2 + 1) + 8 * n4 == mcp_lib.mcp_packed_len(N, K)
     assert np.array_equal(p[:N], mu) and not np.signbit(p[2]) and np.all(p[N:n4] == 0)
-    Lp = p[n4:n4 + n4 * (n4 + 1) // 2]
-    for i in range(n4):
-        for j in range(i + 1):
-            want = L[i, j] if i < N else 0.0
-            assert Lp[i * (i + 1) // 2 + j] == want
-    Wp = p[n4 + n4 * (n4 + 1) // 2:].reshape(8, n4)
+    Lp = p[n4:n4 + n4 * (n4 // 2 + 1)]
+    for m in range(n4 // 2):                      # row pairs (2m, 2m+1), columns interleaved
+        for j in range(2 * m + 2):
+            for h in range(2):
+                i = 2 * m + h
+                want = L[i, j] if (i < N and j <= i) else 0.0
+                assert Lp[2 * m * (m + 1) + 2 * j + h] == want
+    Wp = p[n4 + n4 * (n4 // 2 + 1):].reshape(8, n4)
     assert np.array_equal(Wp[:K, :N], W) and np.all(Wp[:K, N:] == 0) and np.all(Wp[K:] == 0)
 
 
@@ -116,11 +118,13 @@ def test_terminal_to_x(mcp_lib):
 def test_argument_errors_are_reported_not_thrown(mcp_lib):
     prm = _ffi.make_params(4, 10, 1)
     prm.n_assets = 0
-    assert mcp_lib.mcp_paths_grid(ctypes.byref(prm), 100) == -1
+    assert mcp_lib.mcp_launch_paths(ctypes.byref(prm), None, 0, 0, 100, None, 100, None) == -1
     assert b"n_assets" in mcp_lib.mcp_last_error()
     prm = _ffi.make_params(4, 10, 1, alpha=0.95)
-    assert mcp_lib.mcp_paths_grid(ctypes.byref(prm), 1_000_000) == (1_000_000 + 255) // 256
-    assert mcp_lib.mcp_paths_grid(ctypes.byref(prm), 10 ** 9) == 8192
+    assert mcp_lib.mcp_launch_paths(ctypes.byref(prm), None, 0, 0, 100, None, 100, None) == -1
+    assert b"NULL device pointer" in mcp_lib.mcp_last_error()
+    prm.alpha = 1.5
+    assert mcp_lib.mcp_launch_quantile(ctypes.byref(prm), 0.5, None, None, None) == -1 and b"alpha" in mcp_lib.mcp_last_error()
     with pytest.raises(ValueError):
         _ffi.make_params(4, 10, 1, compounding="weird")
 
