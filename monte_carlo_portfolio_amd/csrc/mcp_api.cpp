@@ -75,6 +75,31 @@ const mcp::launch_paths_fn k_launch[16] = {
     mcp::launch_paths_nb9,  mcp::launch_paths_nb10, mcp::launch_paths_nb11, mcp::launch_paths_nb12,
     mcp::launch_paths_nb13, mcp::launch_paths_nb14, mcp::launch_paths_nb15, mcp::launch_paths_nb16};
 
+// Box-Muller tables, one device-resident copy per device, built on first use by tables_init_kernel on
+// the caller's stream (so later launches on that stream are ordered after it).  The first call on a
+// device allocates: do it once before capturing launches into a hipGraph.
+constexpr int MAX_DEVICES = 64;
+std::mutex g_tab_mu;
+float2* g_tables[MAX_DEVICES] = {nullptr};
+
+int device_tables(hipStream_t stream, const float2** out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= MAX_DEVICES) return fail(MCP_E_UNSUPPORTED, "device index %d", dev);
+  std::lock_guard<std::mutex> lock(g_tab_mu);
+  if (!g_tables[dev]) {
+    float2* t = nullptr;
+    if (hipMalloc((void**)&t, 2 * mcp::BM_TAB * sizeof(float2)) != hipSuccess)
+      return fail(MCP_E_NOMEM, "hipMalloc of the Box-Muller tables failed");
+    hipError_t e = mcp::launch_tables_init(t, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);     // other streams may use the tables next
+    if (e != hipSuccess) { (void)hipFree(t); return fail(MCP_E_NODEVICE, "tables_init_kernel: %s", hipGetErrorString(e)); }
+    g_tables[dev] = t;
+  }
+  *out = g_tables[dev];
+  return MCP_OK;
+}
+
 }  // namespace
 
 struct mcp_ctx {
@@ -172,6 +197,9 @@ int mcp_launch_paths(const mcp_params* prm, const float* d_packed, uint64_t seed
   if (paths_per_thread(prm) == 2) variant |= mcp::VAR_PPT2;
   const int kt = (variant & mcp::VAR_KT8) ? KT_WIDE : 1;
   mcp::PathArgs a;
+  const float2* tables = nullptr;
+  if (int rc = device_tables((hipStream_t)stream, &tables)) return rc;
+  a.tables = tables;
   a.packed = d_packed;
   a.terminal = d_terminal;
   a.seed = seed;

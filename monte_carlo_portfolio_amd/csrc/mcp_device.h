@@ -59,14 +59,14 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
   x[0] = c0; x[1] = c1; x[2] = c2; x[3] = c3;
 }
 
-// -2*log1p(f) = -2 f + f^2 Q(f) on [sqrt(.5)-1, sqrt(2)-1]; coefficients from tools/fit_coeffs.py.
-constexpr float LQ0 = 0x1.fffff4p-1f, LQ1 = -0x1.5557acp-1f, LQ2 = 0x1.000688p-1f, LQ3 = -0x1.98a664p-2f;
-constexpr float LQ4 = 0x1.52fdf6p-2f, LQ5 = -0x1.32c6c8p-2f, LQ6 = 0x1.27c4a8p-2f, LQ7 = -0x1.65b8e2p-3f;
-constexpr float NEG_2LN2 = -0x1.62e43p+0f;
-// sin(a) = a + a^3 S(a^2), cos(a) = 1 - a^2/2 + a^4 C(a^2) on |a| <= pi/4.
+constexpr float NEG_2LN2 = -0x1.62e43p+0f;       // -2 ln 2
+constexpr float TWO_PI_2M32 = 0x1.921fb6p-30f;   // 2 pi / 2^32
+// sin(a) = a + a^3 S(a^2), cos(a) = 1 - a^2/2 + a^4 C(a^2) on |a| <= pi/4 (tools/fit_coeffs.py); used
+// only to BUILD the sin/cos table.
 constexpr float SS0 = -0x1.55554p-3f, SS1 = 0x1.1105b4p-7f, SS2 = -0x1.98da62p-13f;
 constexpr float CC0 = 0x1.55554ap-5f, CC1 = -0x1.6c0c8cp-10f, CC2 = 0x1.9a0256p-16f;
-constexpr float TWO_PI_2M32 = 0x1.921fb6p-30f;
+
+constexpr int BM_TAB = 1024;   // entries of each Box-Muller table (float2): 8 KiB + 8 KiB of LDS per block
 
 __device__ __forceinline__ float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
@@ -83,45 +83,77 @@ __device__ __forceinline__ float sqrt_rn(float t) {
   return s;
 }
 
-// Exact-arithmetic Box-Muller pair (SPEC.md section 3).  (xa, xb) -> (s sin(theta), s cos(theta)),
-// u = fl(xa) 2^-32 + 2^-32, s = sqrt(-2 ln u), theta = 2 pi xb 2^-32.
+// ---- table construction (SPEC.md section 3.1; run once per device by tables_init_kernel) -----------
+// (sin, cos)(2 pi xb / 2^32): exact integer quadrant reduction + fixed fp32 polynomials.
+__device__ __forceinline__ void sincos_poly(uint32_t xb, float& sn_out, float& cs_out) {
+  const uint32_t y = xb + 0x20000000u;
+  const int32_t r = (int32_t)(xb << 2) >> 2;
+  const float a = (float)r * TWO_PI_2M32;
+  const float a2 = a * a;
+  float ps = fma32(a2, SS2, SS1); ps = fma32(a2, ps, SS0);
+  const float sn = fma32(a * a2, ps, a);
+  float pc = fma32(a2, CC2, CC1); pc = fma32(a2, pc, CC0);
+  const float cs = fma32(a2 * a2, pc, fma32(a2, -0.5f, 1.0f));
+  const uint32_t kq = y >> 30;
+  float vs = (kq & 1u) ? cs : sn;
+  float vc = (kq & 1u) ? sn : cs;
+  if (kq & 2u) vs = -vs;
+  if (kq == 1u || kq == 2u) vc = -vc;
+  sn_out = vs + 0.0f;
+  cs_out = vc + 0.0f;
+}
+
+// ln(x), x in [0.7, 1.42], binary64 atanh series: IEEE +,*,/ only (identical on host and device).
+__device__ __forceinline__ double ln_series(double x) {
+  const double y = (x - 1.0) / (x + 1.0), y2 = y * y;
+  double s = 0.0;
+  for (int n = 17; n >= 0; n--) s = s * y2 + 1.0 / (double)(2 * n + 1);
+  return 2.0 * y * s;
+}
+
+__device__ __forceinline__ float2 log_table_entry(uint32_t j) {
+  const uint32_t lo = 0x3f3504f3u + (j << 13);
+  float c = __uint_as_float(lo + 0x1000u);
+  if (lo <= 0x3f800000u && 0x3f800000u < lo + 0x2000u) c = 1.0f;
+  const float inv_c = 1.0f / c;
+  const float l2 = (c == 1.0f) ? 0.0f : (float)(-2.0 * ln_series(1.0 / (double)inv_c));
+  return make_float2(inv_c, l2);
+}
+
+// Exact-arithmetic, table-driven Box-Muller pair (SPEC.md section 3).  (xa, xb) -> (s sin th, s cos th),
+// u = fl(xa) 2^-32 + 2^-32, s = sqrt(-2 ln u), th = 2 pi xb 2^-32.  sc / lg point at the LDS copies of the
+// tables.  NATIVE: hardware v_log/v_sqrt/v_sin/v_cos approximations, no tables (not bit-reproducible).
 template <bool NATIVE>
-__device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float& z_sin, float& z_cos) {
+__device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, const float2* sc, const float2* lg,
+                                           float& z_sin, float& z_cos) {
   const float u = fma32((float)xa, 0x1p-32f, 0x1p-32f);
   if constexpr (NATIVE) {
-    // hardware approximations: v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (input in turns)
     const float t = __builtin_amdgcn_logf(u) * NEG_2LN2;
     const float s = __builtin_amdgcn_sqrtf(t);
     const float turns = (float)xb * 0x1p-32f;
     z_sin = s * __builtin_amdgcn_sinf(turns);
     z_cos = s * __builtin_amdgcn_cosf(turns);
   } else {
+    // radius: u = 2^k m, m in [sqrt(.5), sqrt(2)); -2 ln u = k(-2 ln 2) + LG[j].y - 2 log1p(r), r = m LG[j].x - 1
     const uint32_t ib = __float_as_uint(u) - 0x3f3504f3u;
     const int32_t k = (int32_t)ib >> 23;
-    const float m = __uint_as_float((ib & 0x007fffffu) + 0x3f3504f3u);
-    const float f = m - 1.0f;
-    float q = LQ7;
-    q = fma32(q, f, LQ6); q = fma32(q, f, LQ5); q = fma32(q, f, LQ4); q = fma32(q, f, LQ3);
-    q = fma32(q, f, LQ2); q = fma32(q, f, LQ1); q = fma32(q, f, LQ0);
-    const float ff = f * f;
-    const float tm = fma32(f, -2.0f, ff * q);
-    const float t = fma32((float)k, NEG_2LN2, tm);
+    const uint32_t mant = ib & 0x007fffffu;
+    const float m = __uint_as_float(mant + 0x3f3504f3u);
+    const float2 e = lg[mant >> 13];
+    const float r = fma32(m, e.x, -1.0f);
+    const float w = r * (r - 2.0f);
+    float t = fma32((float)k, NEG_2LN2, e.y);
+    t = t + w;
     const float s = sqrt_rn(t);
-    const uint32_t y = xb + 0x20000000u;
-    const int32_t r = (int32_t)(xb << 2) >> 2;
-    const float a = (float)r * TWO_PI_2M32;
-    const float a2 = a * a;
-    float ps = fma32(a2, SS2, SS1); ps = fma32(a2, ps, SS0);
-    const float sn = fma32(a * a2, ps, a);
-    float pc = fma32(a2, CC2, CC1); pc = fma32(a2, pc, CC0);
-    const float cs = fma32(a2 * a2, pc, fma32(a2, -0.5f, 1.0f));
-    const bool swap = (y & 0x40000000u) != 0u;
-    const float vs = swap ? cs : sn;
-    const float vc = swap ? sn : cs;
-    const uint32_t sign_s = y & 0x80000000u;
-    const uint32_t sign_c = (y ^ (y << 1)) & 0x80000000u;
-    z_sin = __uint_as_float(__float_as_uint(s) ^ sign_s) * vs;
-    z_cos = __uint_as_float(__float_as_uint(s) ^ sign_c) * vc;
+    // angle: table point i = round(xb / 2^22), residual d in [-pi/1024, pi/1024): sin d ~ d, cos d ~ 1 - d^2/2
+    const float2 p = sc[(xb + 0x00200000u) >> 22];
+    const int32_t rr = (int32_t)(xb << 10) >> 10;
+    const float d = (float)rr * TWO_PI_2M32;
+    const float cd = fma32(d * -0.5f, d, 1.0f);
+    const float sn = fma32(p.y, d, p.x * cd);
+    const float cs = fma32(-p.x, d, p.y * cd);
+    z_sin = s * sn;
+    z_cos = s * cs;
   }
 }
 

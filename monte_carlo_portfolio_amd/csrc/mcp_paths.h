@@ -17,6 +17,9 @@
 #include "../../include/mcport.h"
 #include "mcp_device.h"
 
+#ifndef MCP_MIN_WAVES
+#define MCP_MIN_WAVES 8     // __launch_bounds__ 2nd argument for N <= 16, one portfolio: 8 waves/SIMD (<= 64 VGPRs)
+#endif
 #ifndef MCP_EXP_VKEYS
 #define MCP_EXP_VKEYS 1
 #endif
@@ -28,6 +31,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct PathArgs {
   const float* __restrict__ packed;   // [mu N4][L row pairs N4(N4/2+1)][W Kpad*N4]  (mcp_pack_params)
   float* __restrict__ terminal;       // [K][stride]
+  const float2* __restrict__ tables;  // [2][BM_TAB]: sin/cos table then log table (built by tables_init_kernel)
   uint64_t seed, path_begin, n_paths, stride;
   int32_t n_steps, n_portfolios, k_begin, compounding;
   float v0;
@@ -58,7 +62,7 @@ constexpr int PATH_BLOCK = 256;
 
 // NB = N4/4 Philox blocks per path-step; KT portfolios per pass; PPT paths per lane.
 template <int NB, int KT, int PPT, bool NATIVE>
-__global__ void __launch_bounds__(PATH_BLOCK) mc_paths_kernel(const PathArgs a) {
+__global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ? MCP_MIN_WAVES : 1) mc_paths_kernel(const PathArgs a) {
   constexpr int N4 = 4 * NB;
   // wave-uniform parameters through the constant address space -> s_load_dword* into SGPRs
   typedef const __attribute__((address_space(4))) float* cfloat_p;
@@ -66,6 +70,12 @@ __global__ void __launch_bounds__(PATH_BLOCK) mc_paths_kernel(const PathArgs a) 
   cfloat_p Lp = mu + N4;
   cfloat_p Wk = mu + N4 + N4 * (N4 / 2 + 1) + (size_t)a.k_begin * N4;
   const int kt = min(KT, a.n_portfolios - a.k_begin);   // live portfolios in this pass (uniform)
+  // Box-Muller tables: 16 KiB of LDS per block, filled once from the device-resident copy
+  __shared__ float2 s_sc[BM_TAB], s_lg[BM_TAB];
+  if constexpr (!NATIVE) {
+    for (int i = threadIdx.x; i < BM_TAB; i += PATH_BLOCK) { s_sc[i] = a.tables[i]; s_lg[i] = a.tables[BM_TAB + i]; }
+    __syncthreads();
+  }
   PhiloxKeys ks = philox_keys((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
 #if MCP_EXP_VKEYS
   // pin the 20 round keys in VGPRs: an SGPR operand halves the issue rate of the xor (profiles/r01_valu_rates.txt)
@@ -103,8 +113,8 @@ __global__ void __launch_bounds__(PATH_BLOCK) mc_paths_kernel(const PathArgs a) 
         for (int e = 0; e < PPT; e++) {
           uint32_t x[4];
           philox4x32_10(blk, 0u, plo[e], phi[e], ks, x);
-          box_muller<NATIVE>(x[0], x[1], z[e][0 * NB + q], z[e][1 * NB + q]);
-          box_muller<NATIVE>(x[2], x[3], z[e][2 * NB + q], z[e][3 * NB + q]);
+          box_muller<NATIVE>(x[0], x[1], s_sc, s_lg, z[e][0 * NB + q], z[e][1 * NB + q]);
+          box_muller<NATIVE>(x[2], x[3], s_sc, s_lg, z[e][2 * NB + q], z[e][3 * NB + q]);
         }
       }
       // r = mu + L z (row i: acc = mu_i, then j ascending), rho_k = sum_i w_ki r_i (i ascending)

@@ -219,6 +219,21 @@ __global__ void stats_kernel(const mcp_params prm, int K, const mcp_moments* __r
   out[k] = s;
 }
 
+// Box-Muller tables (SPEC.md section 3.1): tables[0..1023] = (sin, cos)(2 pi i/1024), tables[1024..2047] = log table.
+__global__ void __launch_bounds__(256) tables_init_kernel(float2* __restrict__ tables) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint32_t)BM_TAB) return;
+  float sn, cs;
+  sincos_poly(i << 22, sn, cs);
+  tables[i] = make_float2(sn, cs);
+  tables[BM_TAB + i] = log_table_entry(i);
+}
+
+hipError_t launch_tables_init(float2* tables, hipStream_t s) {
+  tables_init_kernel<<<BM_TAB / 256, 256, 0, s>>>(tables);
+  return hipGetLastError();
+}
+
 __global__ void select_init_kernel(int K, uint64_t rank_lo, uint64_t rank_hi, SelectState* __restrict__ state) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * K) return;

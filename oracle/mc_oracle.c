@@ -64,42 +64,31 @@ MCO_INLINE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 MCO_INLINE float u32_as_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 MCO_INLINE uint32_t f32_as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
-/* ---- Box-Muller pair, SPEC.md section 3.  Coefficients: tools/fit_coeffs.py. ---------------- */
-/* -2*log1p(f) = -2 f + f^2 Q(f),  f in [sqrt(.5)-1, sqrt(2)-1],  Q degree 7 */
-#define LQ0  0x1.fffff4p-1f
-#define LQ1 -0x1.5557acp-1f
-#define LQ2  0x1.000688p-1f
-#define LQ3 -0x1.98a664p-2f
-#define LQ4  0x1.52fdf6p-2f
-#define LQ5 -0x1.32c6c8p-2f
-#define LQ6  0x1.27c4a8p-2f
-#define LQ7 -0x1.65b8e2p-3f
+/* ---- Box-Muller pair, SPEC.md section 3: table-driven, exact arithmetic ------------------------
+ * Two 1024-entry tables (on the GPU they live in LDS):
+ *   SC[i] = (sin, cos)(2 pi i / 1024)            built with the fixed fp32 polynomial below
+ *   LG[j] = (inv_c, -2 ln(1/inv_c))               c = midpoint of mantissa bin j of [sqrt(.5), sqrt(2)),
+ *                                                 the bin holding 1.0 uses c = 1 exactly
+ * Table construction uses only IEEE +,*,/,fma (binary32 and binary64), so it is reproducible
+ * bit for bit on any IEEE machine; the HIP side builds the same tables in a device init kernel.  */
 #define NEG_2LN2 -0x1.62e43p+0f          /* -2 ln 2 rounded to binary32 */
-/* sin(a) = a + a^3 S(a^2), cos(a) = 1 - a^2/2 + a^4 C(a^2), |a| <= pi/4 */
+#define TWO_PI_2M32 0x1.921fb6p-30f      /* 2 pi / 2^32 rounded to binary32 */
+/* sin(a) = a + a^3 S(a^2), cos(a) = 1 - a^2/2 + a^4 C(a^2), |a| <= pi/4 (tools/fit_coeffs.py) */
 #define SS0 -0x1.55554p-3f
 #define SS1  0x1.1105b4p-7f
 #define SS2 -0x1.98da62p-13f
 #define CC0  0x1.55554ap-5f
 #define CC1 -0x1.6c0c8cp-10f
 #define CC2  0x1.9a0256p-16f
-#define TWO_PI_2M32 0x1.921fb6p-30f      /* 2 pi / 2^32 rounded to binary32 */
 
-MCO_INLINE void box_muller(uint32_t xa, uint32_t xb, float *z_sin, float *z_cos)
+#define MCO_TAB 1024
+static float g_sc[MCO_TAB][2];
+static float g_lg[MCO_TAB][2];
+static pthread_once_t g_tab_once = PTHREAD_ONCE_INIT;
+
+/* (sin, cos)(2 pi xb / 2^32): exact integer quadrant reduction + degree-7/8 polynomials */
+static void sincos_poly(uint32_t xb, float *sn_out, float *cs_out)
 {
-    /* radius: u in [2^-32, 1] */
-    float u = fmaf((float)xa, 0x1p-32f, 0x1p-32f);
-    uint32_t ib = f32_as_u32(u) - 0x3f3504f3u;              /* sqrt(.5) split */
-    int32_t k = (int32_t)ib >> 23;
-    float m = u32_as_f32((ib & 0x007fffffu) + 0x3f3504f3u);  /* [sqrt(.5), sqrt(2)) */
-    float f = m - 1.0f;
-    float q = LQ7;
-    q = fmaf(q, f, LQ6); q = fmaf(q, f, LQ5); q = fmaf(q, f, LQ4); q = fmaf(q, f, LQ3);
-    q = fmaf(q, f, LQ2); q = fmaf(q, f, LQ1); q = fmaf(q, f, LQ0);
-    float ff = f * f;
-    float tm = fmaf(f, -2.0f, ff * q);                       /* -2 log(m) */
-    float t = fmaf((float)k, NEG_2LN2, tm);                  /* -2 log(u) >= 0 */
-    float s = sqrtf(t);
-    /* angle: theta = 2 pi xb / 2^32 = kq*pi/2 + a, |a| <= pi/4, exact integer reduction */
     uint32_t y = xb + 0x20000000u;
     int32_t r = (int32_t)(xb << 2) >> 2;                     /* xb - kq*2^30, in [-2^29, 2^29) */
     float a = (float)r * TWO_PI_2M32;
@@ -108,13 +97,67 @@ MCO_INLINE void box_muller(uint32_t xa, uint32_t xb, float *z_sin, float *z_cos)
     float sn = fmaf(a * a2, ps, a);
     float pc = fmaf(a2, CC2, CC1); pc = fmaf(a2, pc, CC0);
     float cs = fmaf(a2 * a2, pc, fmaf(a2, -0.5f, 1.0f));
-    uint32_t swap = y & 0x40000000u;                         /* kq odd */
-    float vs = swap ? cs : sn;
-    float vc = swap ? sn : cs;
-    uint32_t sign_s = y & 0x80000000u;                       /* kq in {2,3} */
-    uint32_t sign_c = (y ^ (y << 1)) & 0x80000000u;          /* kq in {1,2} */
-    *z_sin = u32_as_f32(f32_as_u32(s) ^ sign_s) * vs;
-    *z_cos = u32_as_f32(f32_as_u32(s) ^ sign_c) * vc;
+    uint32_t kq = y >> 30;                                   /* theta = kq*pi/2 + a */
+    float vs = (kq & 1u) ? cs : sn;
+    float vc = (kq & 1u) ? sn : cs;
+    if (kq & 2u) vs = -vs;                                   /* kq in {2,3} */
+    if (kq == 1u || kq == 2u) vc = -vc;
+    *sn_out = vs + 0.0f; *cs_out = vc + 0.0f;                /* -0 -> +0 */
+}
+
+/* ln(x) for x in [0.7, 1.42], binary64, atanh series: only IEEE +,*,/ (no libm) */
+static double ln_series(double x)
+{
+    double y = (x - 1.0) / (x + 1.0), y2 = y * y, s = 0.0;
+    for (int n = 17; n >= 0; n--) s = s * y2 + 1.0 / (double)(2 * n + 1);
+    return 2.0 * y * s;
+}
+
+static void build_tables(void)
+{
+    for (uint32_t i = 0; i < MCO_TAB; i++) sincos_poly(i << 22, &g_sc[i][0], &g_sc[i][1]);
+    for (uint32_t j = 0; j < MCO_TAB; j++) {
+        uint32_t lo = 0x3f3504f3u + (j << 13);
+        float c = u32_as_f32(lo + 0x1000u);
+        if (lo <= 0x3f800000u && 0x3f800000u < lo + 0x2000u) c = 1.0f;
+        float inv_c = 1.0f / c;
+        g_lg[j][0] = inv_c;
+        g_lg[j][1] = (c == 1.0f) ? 0.0f : (float)(-2.0 * ln_series(1.0 / (double)inv_c));
+    }
+}
+
+void mco_tables(float *sc /* [1024*2] */, float *lg /* [1024*2] */)
+{
+    pthread_once(&g_tab_once, build_tables);
+    memcpy(sc, g_sc, sizeof g_sc);
+    memcpy(lg, g_lg, sizeof g_lg);
+}
+
+/* sqrt: IEEE correctly rounded (sqrtss). */
+MCO_INLINE void box_muller(uint32_t xa, uint32_t xb, float *z_sin, float *z_cos)
+{
+    /* radius: u in [2^-32, 1], u = 2^k m, m in [sqrt(.5), sqrt(2)), -2 ln u = k(-2 ln 2) + LG[j] - 2 log1p(r) */
+    float u = fmaf((float)xa, 0x1p-32f, 0x1p-32f);
+    uint32_t ib = f32_as_u32(u) - 0x3f3504f3u;
+    int32_t k = (int32_t)ib >> 23;
+    uint32_t mant = ib & 0x007fffffu;
+    float m = u32_as_f32(mant + 0x3f3504f3u);
+    uint32_t j = mant >> 13;
+    float r = fmaf(m, g_lg[j][0], -1.0f);                    /* (m - c')/c', c' = 1/inv_c */
+    float w = r * (r - 2.0f);                                /* -2 log1p(r) to O(r^3) */
+    float t = fmaf((float)k, NEG_2LN2, g_lg[j][1]);
+    t = t + w;
+    float s = sqrtf(t);
+    /* angle: theta = 2 pi xb / 2^32 = theta_i + d, table point i, |d| <= pi/1024 */
+    uint32_t i = (xb + 0x00200000u) >> 22;
+    int32_t rr = (int32_t)(xb << 10) >> 10;                  /* xb - i*2^22, in [-2^21, 2^21) */
+    float d = (float)rr * TWO_PI_2M32;
+    float sc = g_sc[i][0], cc = g_sc[i][1];
+    float cd = fmaf(d * -0.5f, d, 1.0f);                     /* cos d */
+    float sn = fmaf(cc, d, sc * cd);                         /* sin(theta_i + d), sin d ~ d */
+    float cs = fmaf(-sc, d, cc * cd);
+    *z_sin = s * sn;
+    *z_cos = s * cs;
 }
 
 /* normals of one path-step: z[m*nb + q] = normal m of Philox block q   (SPEC.md section 2) */
@@ -137,6 +180,7 @@ void mco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 
 void mco_box_muller(uint32_t xa, uint32_t xb, float *z_sin, float *z_cos)
 {
+    pthread_once(&g_tab_once, build_tables);
     box_muller(xa, xb, z_sin, z_cos);
 }
 
@@ -144,6 +188,7 @@ void mco_box_muller(uint32_t xa, uint32_t xb, float *z_sin, float *z_cos)
 MCO_CLONES
 void mco_box_muller_n(const uint32_t *xa, const uint32_t *xb, float *z_sin, float *z_cos, uint64_t n)
 {
+    pthread_once(&g_tab_once, build_tables);
     for (uint64_t i = 0; i < n; i++) box_muller(xa[i], xb[i], &z_sin[i], &z_cos[i]);
 }
 
@@ -151,6 +196,7 @@ MCO_CLONES
 void mco_step_normals(uint64_t seed, uint64_t path, uint32_t step, int n_assets, float *z /* [4*ceil(N/4)] */)
 {
     int nb = (n_assets + 3) / 4;
+    pthread_once(&g_tab_once, build_tables);
     step_normals((uint32_t)seed, (uint32_t)(seed >> 32), path, step, nb, z);
 }
 
@@ -214,6 +260,7 @@ int mco_simulate(int n_assets, int n_steps, int n_portfolios, int compounding, f
 {
     if (n_assets < 1 || n_assets > MCO_MAX_ASSETS || n_steps < 0 || n_portfolios < 1) return -1;
     if (n_threads < 1) n_threads = 1;
+    pthread_once(&g_tab_once, build_tables);
     if ((uint64_t)n_threads > n_paths) n_threads = n_paths ? (int)n_paths : 1;
     mco_job *jobs = (mco_job *)malloc(sizeof(mco_job) * n_threads);
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * n_threads);

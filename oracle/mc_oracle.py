@@ -35,6 +35,8 @@ def lib() -> ctypes.CDLL:
         L.mco_box_muller_n.restype = None
         L.mco_step_normals.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, _f32p]
         L.mco_step_normals.restype = None
+        L.mco_tables.argtypes = [_f32p, _f32p]
+        L.mco_tables.restype = None
         L.mco_simulate.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                    _f32p, _f32p, _f32p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                    _f32p, ctypes.c_int]
@@ -56,6 +58,14 @@ def box_muller(xa, xb):
     zc = np.empty(xa.shape, np.float32)
     lib().mco_box_muller_n(xa, xb, zs, zc, xa.size)
     return zs, zc
+
+
+def tables():
+    """(SC [1024,2], LG [1024,2]) float32 tables of SPEC.md section 3."""
+    sc = np.zeros((1024, 2), np.float32)
+    lg = np.zeros((1024, 2), np.float32)
+    lib().mco_tables(sc, lg)
+    return sc, lg
 
 
 def step_normals(seed: int, path: int, step: int, n_assets: int) -> np.ndarray:
