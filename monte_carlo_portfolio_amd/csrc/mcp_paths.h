@@ -18,7 +18,7 @@
 #include "mcp_device.h"
 
 #ifndef MCP_MIN_WAVES
-#define MCP_MIN_WAVES 8     // __launch_bounds__ 2nd argument for N <= 16, one portfolio: 8 waves/SIMD (<= 64 VGPRs)
+#define MCP_MIN_WAVES 7     // __launch_bounds__ 2nd argument for N <= 16, one portfolio: caps the kernel at 64 VGPRs (8 waves/SIMD) without spills
 #endif
 #ifndef MCP_EXP_VKEYS
 #define MCP_EXP_VKEYS 1
