@@ -26,10 +26,14 @@ import numpy as np  # noqa: E402
 N_ASSETS, N_STEPS, PATHS_PER_GPU = 16, 252, 1_000_000
 MODEL_FLOPS_PER_PATH = N_STEPS * (N_ASSETS * N_ASSETS + 3 * N_ASSETS + 2)     # 77,112
 HBM_BYTES_PER_PATH = 4                                                          # V_T store
-# VALU-issue ceiling of the unfolded model: per wave and path-step 80 widening
-# multiplies + 32 transcendentals + 329 full-rate ops at the issue costs measured on this chip at 8
-# waves/SIMD (profiles/r01_valu_rates.txt): 4.7, 8.2, 2.6 cycles -> 1,494 cycles; 1,024 SIMDs x 2.4 GHz.
-ISSUE_CYCLES_PER_WAVE_STEP = 80 * 4.7 + 32 * 8.2 + (120 + 56 + 153) * 2.6
+# VALU-issue ceiling: the cheapest instruction mix that implements north_star's
+# algorithm (Philox4x32-10 -> Box-Muller on hardware transcendentals -> triangular GEMV -> weight dot ->
+# compounding), per wave and path-step at N = 16, priced at the issue costs measured on this chip at 8
+# waves/SIMD (profiles/r01_valu_rates.txt):
+#   Philox   80 v_mad_u64_u32 x 4.7 + 80 three-input xor x 2.6                            =  584
+#   8 pairs  2 cvt x 4.4 + 4 transcendentals x 8.2 + 5 packed fp ops x 2.15               =  419
+#   GEMV     136 FMA as 68 v_pk_fma_f32 x 4.3; weight dot 8 v_pk_fma_f32; compound 1 x 2.6 =  329
+ISSUE_CYCLES_PER_WAVE_STEP = (80 * 4.7 + 80 * 2.6) + 8 * (2 * 4.4 + 4 * 8.2 + 5 * 2.15) + (68 * 4.3 + 8 * 4.3 + 2.6)
 VALU_CEILING_PATHS_PER_S = 1024 * 2.4e9 * 64 / (ISSUE_CYCLES_PER_WAVE_STEP * N_STEPS)
 HBM_PEAK_GBS = 8000.0
 FP32_VECTOR_PEAK_TFLOPS = 157.3
@@ -117,6 +121,22 @@ def main():
     torch.cuda.synchronize()
     k_ms = ev0.elapsed_time(ev1) / n_k
 
+    # the hardware-transcendental variant of the same kernel (tolerance parity), for the record
+    native = None
+    if world == 1 and not args.native_math:
+        eng_n = PathEngine(mu32, L, W32, N_STEPS, PATHS_PER_GPU, native_math=True)
+        eng_n.launch_paths_only(seed)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(n_k):
+            eng_n.launch_paths_only(seed)
+        ev1.record()
+        torch.cuda.synchronize()
+        nk_ms = ev0.elapsed_time(ev1) / n_k
+        native = {"kernel_ms": nk_ms, "kernel_paths_per_s": PATHS_PER_GPU / (nk_ms * 1e-3),
+                  "frac": PATHS_PER_GPU / (nk_ms * 1e-3) / VALU_CEILING_PATHS_PER_S,
+                  "note": "MCP_FLAG_NATIVE_MATH: v_log/v_sqrt/v_sin/v_cos Box-Muller, tolerance parity (SPEC.md section 6)"}
+
     if rank == 0:
         total_paths = PATHS_PER_GPU * world * args.steps
         value = total_paths / elapsed
@@ -130,7 +150,7 @@ def main():
                 traffic = None
         roofline = {
             "bound": "valu",
-            "kernel": "mc_paths_kernel<NB=4,KT=1>",
+            "kernel": "mc_paths_kernel<4,1,1,false>",
             "achieved": MODEL_FLOPS_PER_PATH * k_paths_s / 1e12,
             "peak": MODEL_FLOPS_PER_PATH * VALU_CEILING_PATHS_PER_S / 1e12,
             "unit": "TFLOP/s",
@@ -139,8 +159,11 @@ def main():
             "kernel_ms": k_ms,
             "kernel_paths_per_s": k_paths_s,
             "note": "VALU-issue bound (SURVEY 0.4/8d): achieved/peak = model fp32 FLOPs (77,112/path) x paths/s; "
-                    "peak is the issue-cycle ceiling of the unfolded instruction mix at measured gfx950 issue costs, "
-                    "not the 157.3 TFLOP/s fp32 vector peak",
+                    "peak = issue-cycle ceiling of the cheapest instruction mix for this algorithm at issue costs "
+                    "measured on gfx950 (1,332 cycles per wave-step, DESIGN.md section 4), not the 157.3 TFLOP/s fp32 "
+                    "vector peak; the exact-math kernel executes table-driven Box-Muller (bit-reproducible) instead of "
+                    "hardware transcendentals",
+            "native_math_kernel": native,
             "frac_of_fp32_vector_peak": MODEL_FLOPS_PER_PATH * k_paths_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
             "hbm": {"achieved": HBM_BYTES_PER_PATH * k_paths_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": HBM_BYTES_PER_PATH * k_paths_s / 1e9 / HBM_PEAK_GBS},
