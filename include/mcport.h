@@ -99,6 +99,16 @@ int mcp_simulate(mcp_ctx *ctx, const mcp_params *prm,
                  float *terminal_out,  /* NULL or host [K*n_paths] */
                  mcp_stats *stats_out  /* [K] */);
 
+/* The reference's own sweep (app.py:699-717) over HISTORICAL returns, loop body app.py:708-713 for P weight
+ * vectors at once, binary64 like the reference.  returns: [R*N] row-major (returns_df.values, app.py:667),
+ * mean/cov: the annualised mean_returns / cov_matrix of app.py:679-680, W: [P*N] (rows as drawn at
+ * app.py:702), rf in the reference's units (user_rf, app.py:711), alpha = cvar_alpha (app.py:684).
+ * Outputs are [P] each.  Limits: N <= MCP_MAX_ASSETS, R <= MCP_SWEEP_MAX_ROWS. */
+#define MCP_SWEEP_MAX_ROWS 4096
+int mcp_sweep_historical(mcp_ctx *ctx, int n_assets, int n_rows, int n_portfolios, const double *returns,
+                         const double *mean, const double *cov, const double *W, double rf, double alpha,
+                         double *port_return, double *port_std, double *sharpe, double *var, double *cvar);
+
 /* ---- device-level API: the same kernels as separate enqueue-only steps, for a host that owns the
  *      buffers and the collectives (one process per GPU, torch.distributed over RCCL).  Work buffers
  *      are opaque device memory of the byte sizes given by mcp_ws_bytes().  Between a *_hist step and

@@ -57,6 +57,7 @@ MOMENTS_DTYPE = np.dtype([("n", np.float64), ("sum", np.float64), ("sumsq", np.f
                           ("min", np.float64), ("max", np.float64)])
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _vp = ctypes.c_void_p
 _u64 = ctypes.c_uint64
 _int = ctypes.c_int
@@ -70,6 +71,8 @@ SIGNATURES = {
     "mcp_ctx_create": (_int, [_int, ctypes.POINTER(_vp)]),
     "mcp_ctx_destroy": (None, [_vp]),
     "mcp_simulate": (_int, [_vp, _PP, _f32p, _f32p, _f32p, _u64, _u64, _u64, _vp, _vp]),
+    "mcp_sweep_historical": (_int, [_vp, _int, _int, _int, _f64p, _f64p, _f64p, _f64p, ctypes.c_double, ctypes.c_double,
+                                    _f64p, _f64p, _f64p, _f64p, _f64p]),
     "mcp_ws_bytes": (ctypes.c_size_t, [_int, _int]),
     "mcp_packed_len": (ctypes.c_size_t, [_int, _int]),
     "mcp_pack_params": (_int, [_int, _int, _f32p, _f32p, _f32p, _f32p, ctypes.c_size_t]),

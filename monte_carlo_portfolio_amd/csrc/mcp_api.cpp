@@ -117,6 +117,8 @@ struct mcp_ctx {
   size_t h_packed_cap = 0;
   mcp_stats* h_stats = nullptr;
   size_t h_stats_cap = 0;
+  double* d_sweep = nullptr;   // inputs then outputs of mcp_sweep_historical
+  size_t sweep_cap = 0;
 };
 
 extern "C" {
@@ -328,6 +330,7 @@ void mcp_ctx_destroy(mcp_ctx* c) {
   if (c->d_terminal) (void)hipFree(c->d_terminal);
   if (c->h_packed) (void)hipHostFree(c->h_packed);
   if (c->h_stats) (void)hipHostFree(c->h_stats);
+  if (c->d_sweep) (void)hipFree(c->d_sweep);
   delete c;
 }
 
@@ -394,6 +397,42 @@ int mcp_simulate(mcp_ctx* c, const mcp_params* prm, const float* mu, const float
     HIP_TRY(hipMemcpyAsync(terminal_out, c->d_terminal, (size_t)K * n_paths * sizeof(float), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   memcpy(stats_out, c->h_stats, (size_t)K * sizeof(mcp_stats));
+  return MCP_OK;
+}
+
+int mcp_sweep_historical(mcp_ctx* c, int N, int R, int P, const double* returns, const double* mean, const double* cov,
+                         const double* W, double rf, double alpha, double* o_ret, double* o_std, double* o_sharpe,
+                         double* o_var, double* o_cvar) {
+  if (!c) return fail(MCP_E_ARG, "ctx is NULL");
+  if (N < 1 || N > MCP_MAX_ASSETS) return fail(MCP_E_ARG, "n_assets=%d outside [1,%d]", N, MCP_MAX_ASSETS);
+  if (R < 1 || R > MCP_SWEEP_MAX_ROWS) return fail(MCP_E_ARG, "n_rows=%d outside [1,%d]", R, MCP_SWEEP_MAX_ROWS);
+  if (P < 1) return fail(MCP_E_ARG, "n_portfolios=%d < 1", P);
+  if (!(alpha > 0.0 && alpha < 1.0)) return fail(MCP_E_ARG, "alpha=%g outside (0,1)", alpha);
+  if (!returns || !mean || !cov || !W || !o_ret || !o_std || !o_sharpe || !o_var || !o_cvar)
+    return fail(MCP_E_ARG, "NULL pointer");
+  std::lock_guard<std::mutex> lock(c->mu);
+  HIP_TRY(hipSetDevice(c->device));
+  uint64_t lo, hi;
+  double gamma;
+  if (int rc = mcp_percentile_rank((uint64_t)R, alpha, &lo, &hi, &gamma)) return rc;
+  const size_t n_ret = (size_t)R * N, n_cov = (size_t)N * N, n_w = (size_t)P * N, n_out = 5 * (size_t)P;
+  const size_t total = n_ret + (size_t)N + n_cov + n_w + n_out;
+  if (int rc = grow_dev((void**)&c->d_sweep, &c->sweep_cap, total * sizeof(double))) return rc;
+  double* d_ret = c->d_sweep;
+  double* d_mean = d_ret + n_ret;
+  double* d_cov = d_mean + N;
+  double* d_w = d_cov + n_cov;
+  double* d_out = d_w + n_w;
+  hipStream_t s = c->stream;
+  HIP_TRY(hipMemcpyAsync(d_ret, returns, n_ret * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_mean, mean, (size_t)N * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_cov, cov, n_cov * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_w, W, n_w * sizeof(double), hipMemcpyHostToDevice, s));
+  HIP_TRY(mcp::launch_sweep_hist(N, R, P, d_ret, d_mean, d_cov, d_w, rf, lo, hi, gamma, d_out, s));
+  double* outs[5] = {o_ret, o_std, o_sharpe, o_var, o_cvar};
+  for (int i = 0; i < 5; i++)
+    HIP_TRY(hipMemcpyAsync(outs[i], d_out + (size_t)i * P, (size_t)P * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return MCP_OK;
 }
 

@@ -46,4 +46,8 @@ hipError_t launch_tail(const mcp_params& prm, int K, const float* terminal, uint
 hipError_t launch_stats(const mcp_params& prm, int K, const mcp_moments* mom, const Quantile* quant,
                         const double* tail, mcp_stats* out, hipStream_t s);
 
+hipError_t launch_sweep_hist(int N, int R, int P, const double* returns, const double* mean, const double* cov,
+                             const double* W, double rf, uint64_t rank_lo, uint64_t rank_hi, double gamma,
+                             double* out5, hipStream_t s);
+
 }  // namespace mcp

@@ -1,0 +1,112 @@
+"""GPU sweep over historical returns against goldens produced
+by RUNNING THE REFERENCE (tests/golden/make_goldens.py: headless app.py under stub streamlit).
+
+Weights are drawn on the host with the reference's own NumPy calls, so for a given np.random.seed the
+arrays line up one to one; scoring runs in the HIP kernel `sweep_hist_kernel` (binary64).  Bar: optimum
+indices exact; risks / returns / metrics within 1e-12 relative (BLAS and the wave reduction associate
+the three- to N-term sums differently).
+"""
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from monte_carlo_portfolio_amd import sweep
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, "golden", "ref_script.json")))
+A = np.load(os.path.join(HERE, "golden", "ref_script_arrays.npz"))
+F = json.load(open(os.path.join(HERE, "golden", "ref_functions.json")))
+
+
+def hx(v):
+    return float.fromhex(v)
+
+
+def returns_frame(key):
+    names = G[key]["asset_names"]
+    return pd.DataFrame(A[f"{key}__returns_df"], columns=names)
+
+
+@pytest.mark.parametrize("key,seed", [("monthly_seed12345", 12345), ("monthly_seed0", 0), ("monthly_seed1", 1),
+                                      ("weekly_seed12345", 12345), ("monthly_collar_seed12345", 12345)])
+def test_all_methods_match_the_reference_run(gpu_ctx, key, seed):
+    e = G[key]
+    base = key.rsplit("_seed", 1)[0] + "_seed12345"       # returns matrix is seed independent
+    rd = returns_frame(base)
+    assert list(rd.shape) == e["returns_shape"]
+    R, mean, cov = sweep.sweep_inputs(rd, e["annual_factor"])
+    np.testing.assert_allclose(mean, [hx(v) for v in e["mean_returns"]], rtol=1e-14)
+    np.testing.assert_allclose(cov, [[hx(v) for v in row] for row in e["cov_matrix"]], rtol=1e-13)
+    res = sweep.run_all_methods(rd, user_rf=e["user_rf"], annual_factor=e["annual_factor"], seed=seed)
+    for m, want in e["methods"].items():
+        got = res[m]
+        assert len(got["all_risks"]) == want["n"]
+        assert got["opt_idx"] == want["opt_idx"], m                         # exact
+        np.testing.assert_allclose(got["all_risks"][got["opt_idx"]] * 100, hx(want["opt_point_pct"][0]), rtol=1e-12)
+        np.testing.assert_allclose(got["all_returns"][got["opt_idx"]] * 100, hx(want["opt_point_pct"][1]), rtol=1e-12)
+        np.testing.assert_allclose(got["dollar_vals"], [hx(v) for v in want["dollar_vals"]], rtol=1e-15)
+        np.testing.assert_allclose([got["all_metrics"].min(), got["all_metrics"].max()],
+                                   [hx(want["metric_min"]), hx(want["metric_max"])], rtol=1e-12)
+        k = f"{key}__{m}__metrics"
+        if k in A:
+            np.testing.assert_allclose(got["all_risks"] * 100, A[f"{key}__{m}__risks_pct"], rtol=1e-12)
+            np.testing.assert_allclose(got["all_returns"] * 100, A[f"{key}__{m}__returns_pct"], rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(got["all_metrics"], A[k], rtol=1e-12, atol=1e-15)
+        if m == "MPT":
+            x, y = sweep.capital_allocation_line(got["all_risks"], got["all_metrics"], e["user_rf"], got["opt_idx"])
+            np.testing.assert_allclose([y[0], y[-1], x[-1]], [hx(want["cal_y_first_last"][0]), hx(want["cal_y_first_last"][1]),
+                                                               hx(want["cal_x_last"])], rtol=1e-12)
+    assert e["n_dirichlet_draws"] == 4 * 2500
+
+
+def test_efficient_frontier_matches_reference_function(gpu_ctx):
+    g = F["G5_efficient_frontier"]
+    mean = np.array([hx(v) for v in g["mean_returns"]])
+    cov = np.array([[hx(v) for v in row] for row in g["cov"]])
+    for tag, kw in {"free": {}, "bounded": {"min_weights": np.array([0.05] * 4), "max_weights": np.array([0.6] * 4)},
+                    "infeasible": {"min_weights": np.array([0.3] * 4), "max_weights": np.array([0.31] * 4)}}.items():
+        np.random.seed(g["seed"])
+        res, W = sweep.efficient_frontier(mean, cov, points=g["points"], **kw)
+        want_w = np.array([[hx(v) for v in row] for row in g["cases"][tag]["weights"]])
+        want_r = np.array([[hx(v) for v in row] for row in g["cases"][tag]["results"]])
+        assert np.array_equal(W, want_w), tag                               # same RNG calls -> same weights
+        np.testing.assert_allclose(res, want_r, rtol=1e-13)
+
+
+def test_constraints_and_skips(gpu_ctx):
+    """Q8: portfolios with no accepted draw are skipped; equal weights outside the bounds fail."""
+    rd = returns_frame("monthly_seed12345")
+    lo, hi = np.array([0.2, 0.2, 0.2]), np.array([0.5, 0.5, 0.5])
+    risks, rets, W, metrics, opt = sweep.run_sweep(rd, "VaR", 300, lo, hi, seed=3)
+    assert len(W) <= 300 and np.all(W >= lo) and np.all(W <= hi) and opt == int(np.argmin(metrics))
+    # the reference's loop, restated on the CPU with its own helper functions' definitions
+    R, mean, cov = sweep.sweep_inputs(rd, 12)
+    for i in (0, len(W) - 1, opt):
+        series = R @ W[i]
+        v = np.percentile(series, (1 - 0.95) * 100)
+        assert metrics[i] == pytest.approx(-v, rel=1e-12)
+        assert risks[i] == pytest.approx(np.sqrt(W[i] @ cov @ W[i]), rel=1e-12)
+    with pytest.raises(IndexError):
+        sweep.run_sweep(rd, "Equal Weight", min_weights=np.array([0.5, 0.0, 0.0]))
+    with pytest.raises(ValueError):
+        sweep.run_sweep(rd, "Monte Carlo", 5, np.array([0.9, 0.9, 0.9]), seed=1)
+
+
+def test_large_sweep_shape(gpu_ctx):
+    """252 rows x 16 assets x 10,000 portfolios (BASELINE configs[4] shape on historical data)."""
+    rng = np.random.default_rng(0)
+    R = rng.normal(0.0005, 0.02, (252, 16))
+    W = np.random.RandomState(7).dirichlet(np.ones(16), 10_000)
+    Rm, mean, cov = sweep.sweep_inputs(R, 252)
+    s = sweep.score_portfolios(Rm, mean, cov, W, rf=0.03)
+    series = R @ W.T
+    np.testing.assert_allclose(s["var_95"], np.percentile(series, (1 - 0.95) * 100, axis=0), rtol=1e-11, atol=1e-15)
+    np.testing.assert_allclose(s["port_return"], W @ mean, rtol=1e-12)
+    np.testing.assert_allclose(s["port_std"], np.sqrt(np.einsum("pi,ij,pj->p", W, cov, W)), rtol=1e-12)
+    want_cvar = np.array([series[:, p][series[:, p] <= s["var_95"][p]].mean() for p in range(0, 10_000, 97)])
+    np.testing.assert_allclose(s["cvar_95"][::97], want_cvar, rtol=1e-11)
+    assert int(np.argmax(s["sharpe"])) == int(np.argmax((W @ mean - 0.03) / np.sqrt(np.einsum("pi,ij,pj->p", W, cov, W))))
