@@ -1,0 +1,190 @@
+"""Host-side surface (ingest, metrics, options: SURVEY.md section 8f-2..4) against goldens produced by RUNNING
+THE REFERENCE's own functions in the build container (tests/golden/make_goldens.py).  CPU only."""
+import io
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from monte_carlo_portfolio_amd import ingest, metrics, options
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "golden", "data")
+F = json.load(open(os.path.join(HERE, "golden", "ref_functions.json")))
+G = json.load(open(os.path.join(HERE, "golden", "ref_script.json")))
+A = np.load(os.path.join(HERE, "golden", "ref_script_arrays.npz"))
+
+
+def hx(v):
+    return float.fromhex(v)
+
+
+def upload(name):
+    b = io.BytesIO(open(os.path.join(DATA, name), "rb").read())
+    b.name = name
+    return b
+
+
+def mk(text, name="x.csv"):
+    b = io.BytesIO(text.encode("utf-8"))
+    b.name = name
+    return b
+
+
+# ---------------------------------------------------------------- G1: read_csv_file
+@pytest.mark.parametrize("name", sorted(F["G1_read_csv_file"]))
+def test_read_csv_file_compat_matches_reference(name):
+    want = F["G1_read_csv_file"][name]
+    errors = []
+    df = ingest.read_csv_file(upload(name), compat=True, report=errors.append)
+    if want["result"] is None:
+        assert df is None and len(errors) == want["n_errors"] == 1            # Q1: thousands separators
+        return
+    assert errors == [] and list(df.columns) == want["columns"] and len(df) == want["rows"]
+    assert [str(t) for t in df.dtypes] == want["dtypes"]
+    assert str(df["Date"].iloc[0].date()) == want["first_date"] and str(df["Date"].iloc[-1].date()) == want["last_date"]
+    assert str(df["Date"].min().date()) == want["min_date"] and str(df["Date"].max().date()) == want["max_date"]
+    for key, val in (("first_price", df["Price"].iloc[0]), ("last_price", df["Price"].iloc[-1]),
+                     ("min_price", df["Price"].min()), ("max_price", df["Price"].max()), ("sum_price", df["Price"].sum())):
+        assert float(val) == hx(want[key]), key
+
+
+@pytest.mark.parametrize("case", sorted(F["G1b_read_csv_synthetic"]))
+def test_read_csv_header_sniffing_and_price_column_choice(case):
+    g = F["G1b_read_csv_synthetic"][case]
+    errors = []
+    df = ingest.read_csv_file(mk(g["text"]), compat=True, report=errors.append)
+    assert len(errors) == g["n_errors"]
+    if g["result"] is None:
+        assert df is None
+    else:
+        assert [str(d.date()) for d in df["Date"]] == g["result"]["dates"]
+        assert [float(p) for p in df["Price"]] == [hx(v) for v in g["result"]["prices"]]
+
+
+def test_default_mode_parses_thousands_separators():
+    """The fix for Q1: every shipped file loads completely; files without separators are unchanged."""
+    for name, want in F["G1_read_csv_file"].items():
+        df = ingest.read_csv_file(upload(name), report=lambda m: None)
+        n_lines = sum(1 for _ in open(os.path.join(DATA, name), encoding="utf-8-sig")) - 1
+        assert df is not None and len(df) == n_lines, name
+        if want["result"] == "ok" and want["rows"] == n_lines:
+            ref = ingest.read_csv_file(upload(name), compat=True)
+            assert df.equals(ref)
+    df = ingest.read_csv_file(mk('Date,Price\n2024-01-01,"1,234.5"\n2024-01-02,999.0\n'))
+    assert list(df["Price"]) == [1234.5, 999.0]
+    btc = ingest.read_csv_file(upload("Bitcoin Historical Data.csv"))
+    assert btc["Price"].iloc[0] == 104780.2 and str(btc["Date"].iloc[0].date()) == "2025-06-02"
+
+
+def test_config0_inputs():
+    """BASELINE configs[0]: BTC/ETH/XAU daily files, thousands parsed, inner join -> 24 rows,
+    daily returns incl. the leading 0.0 row, positive-definite covariance; the reference's own loader
+    rejects all three (golden)."""
+    assert G["config0_reference_loader"] == {"n_errors": 3, "uploaded": 0, "has_returns_df": False}
+    files = [upload(n) for n in ("Bitcoin Historical Data.csv", "Ethereum Historical Data.csv", "XAU_USD Historical Data.csv")]
+    names, prices, res = ingest.load_prices(files, resample_rule="D", report=lambda m: None)
+    assert names == ["Bitcoin Historical Data", "Ethereum Historical Data", "XAU_USD Historical Data"]
+    assert len(prices) == 24 and str(prices.index.min().date()) == "2025-05-02" and str(prices.index.max().date()) == "2025-06-02"
+    rets = ingest.returns_matrix(res)
+    assert rets.shape == (24, 3) and (rets.iloc[0] == 0).all()
+    assert np.linalg.eigvalsh(rets.cov().values).min() > 0
+    with pytest.raises(ValueError):
+        ingest.load_prices(files, compat=True, report=lambda m: None)
+
+
+# ---------------------------------------------------------------- G2/G3: tab-0 pipeline
+@pytest.mark.parametrize("key,rule", [("monthly_seed12345", "M"), ("weekly_seed12345", "W")])
+def test_alignment_resampling_returns_and_stats_table(key, rule):
+    e = G[key]
+    files = [upload(f) for f in G["files"]]
+    names, prices, res = ingest.load_prices(files, resample_rule=rule, compat=True)
+    assert names == e["asset_names"] and len(prices) == e["prices_rows"]
+    assert [str(d.date()) for d in res.index] == e["resampled_index"]
+    assert np.array_equal(res.values, A[f"{key}__resampled_prices"])
+    rets = ingest.returns_matrix(res)
+    assert np.array_equal(rets.values, A[f"{key}__returns_df"]) and list(rets.shape) == e["returns_shape"]
+    assert ingest.ANNUAL_FACTOR[rule] == e["annual_factor"]
+    table = metrics.stats_table(res, freq=rule, risk_free=e["user_rf"])
+    assert list(table.columns) == e["stats_columns"]
+    want = np.array([[hx(v) for v in row] for row in e["stats_df"]])
+    np.testing.assert_array_equal(table.values.astype(float), want)
+
+
+def test_collar_overlay_changes_the_returns_matrix():
+    e = G["monthly_collar_seed12345"]
+    files = [upload(f) for f in G["files"]]
+    names, prices, res = ingest.load_prices(files, resample_rule="M", compat=True)
+    S = res["Cardano Historical Data"].iloc[-1]
+    rows = {"Cardano Historical Data": options.strategy_rows("Collar", S, premium_put=0.01, premium_call=0.02)}
+    rets = ingest.returns_matrix(res, rows)
+    assert np.array_equal(rets.values, A["monthly_collar_seed12345__returns_df"])
+    assert not np.array_equal(rets.values, A["monthly_seed12345__returns_df"])
+
+
+def test_dedupe_names():
+    assert ingest.dedupe_names(["a", "b", "a", "a"]) == ["a", "b", "a (2)", "a (3)"]
+    assert ingest.asset_name("BTC_USD 7 Years Weekly.csv") == "BTC_USD 7 Years Weekly"
+    assert ingest.asset_name("x.y.csv") == "x"
+
+
+# ---------------------------------------------------------------- G6 + scalar metrics
+def test_var_cvar_known_answers():
+    for g in F["G6_var_cvar"]:
+        x = np.random.RandomState(g["rs_seed"]).standard_normal(g["n"]) * 0.05
+        if g["kind"] == "ties":
+            x = np.round(x, 2)
+        if "x" in g:
+            assert [float(v) for v in x] == [hx(v) for v in g["x"]]
+        assert metrics.var(x, g["alpha"]) == hx(g["var"])
+        assert metrics.cvar(pd.Series(x), g["alpha"]) == hx(g["cvar"])
+        assert metrics.cvar(x, g["alpha"]) == hx(g["cvar_ndarray"])
+
+
+def test_scalar_metrics():
+    g = F["G_metrics"]
+    r = pd.Series([hx(v) for v in g["returns"]])
+    assert metrics.sharpe_ratio(r, 3.0, 12) == hx(g["sharpe_ratio"]) and metrics.sharpe_ratio(r) == hx(g["sharpe_ratio_rf0"])
+    assert metrics.sortino_ratio(r, 3.0, 12) == hx(g["sortino_ratio"])
+    assert metrics.sortino_ratio(r.abs() + 1.0, 0, 12) == hx(g["sortino_all_positive"])
+    assert metrics.annual_volatility(r, 52) == hx(g["annual_volatility"]) and metrics.annual_return(r, 12) == hx(g["annual_return"])
+    assert metrics.max_drawdown(r) == hx(g["max_drawdown"]) and metrics.sharpe_ratio(pd.Series([0.01] * 5)) == hx(g["sharpe_zero_std"])
+
+
+# ---------------------------------------------------------------- G7/G8: options
+def test_payoff_breakeven_and_pl_percent():
+    g = F["G7_payoff"]
+    S, pp = g["current_price"], g["purchase_price"]
+    grid = options.payoff_grid(S)
+    for name, c in g["cases"].items():
+        rows = [tuple(r) for r in c["rows"]]
+        pay = options.calculate_payoff(rows, S, pp, grid)
+        assert pay == [hx(v) for v in c["payoff"]], name
+        assert options.calculate_breakeven(rows, pp) == hx(c["breakeven"]), name
+        assert options.calculate_profit_loss_percent(pay, pp, 2.0) == [hx(v) for v in c["pl_percent"]]
+        assert options.calculate_profit_loss_percent(pay[:3], pp, 0.0) == [hx(v) for v in c["pl_percent_zero_investment"]]
+
+
+def test_options_series_every_row_type():
+    g = F["G8_options_series"]
+    prices = pd.Series([hx(v) for v in g["prices"]], index=pd.date_range("2024-01-31", periods=13, freq="ME"))
+    for t in options.ROW_TYPES + ("unknown",):
+        got = options.calc_options_series([(t, 100.0, 1.5, 2.0)], prices)
+        assert list(got) == [hx(v) for v in g[t]], t
+        assert got.index.equals(prices.index)
+    collar = [(options.BUY_ASSET, 0, 0, 1.0), (options.LONG_PUT, 95.0, 1.0, 1.0), (options.SHORT_CALL, 108.0, 0.8, 1.0)]
+    assert list(options.calc_options_series(collar, prices)) == [hx(v) for v in g["collar"]]
+    assert list(options.calc_options_series([(options.BUY_ASSET, 0, 0, 1.0)], pd.Series([0.0, 1.0, 2.0]))) == [hx(v) for v in g["zero_prev"]]
+    assert options.calc_option_return(options.LONG_CALL, 110.0, 100.0, 105.0, 1.0, 99) == (5.0 - 1.0) / 100.0
+    assert options.calc_option_return(options.LONG_CALL, 110.0, 0.0, 105.0, 1.0, 1) == 0
+
+
+def test_strategy_table_defaults():
+    rows = options.strategy_rows("Protective Put", 100.0, qty_asset=2.0)
+    assert rows == [(options.BUY_ASSET, 0, 0, 2.0), (options.LONG_PUT, 90.0, 0.0, 1.0)]
+    assert options.strategy_rows("-", 100.0) == [] and len(options.strategy_rows("Collar", 50.0)) == 2
+    assert options.strategy_rows("Synthetic Put", 80.0)[1][:2] == (options.LONG_CALL, 80.0)
+    with pytest.raises(ValueError):
+        options.strategy_rows("nope", 1.0)
