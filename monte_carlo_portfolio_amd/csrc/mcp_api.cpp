@@ -38,10 +38,12 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 constexpr int KT_WIDE = 8;           // portfolios per pass of the KT=8 kernel
+constexpr int K_PAD = 128;           // W rows are zero-padded to a multiple of this (MFMA sweep tile: 32*MT)
+constexpr int SWEEP_MIN_K = 17;      // from this many portfolios on (and N <= 16) the MFMA sweep kernel runs
 constexpr int GRID_CAP = 8192;       // path-kernel blocks; tiles beyond are grid-strided
 
 inline int n4_of(int n) { return 4 * ((n + 3) / 4); }
-inline int kpad_of(int k) { return KT_WIDE * ((k + KT_WIDE - 1) / KT_WIDE); }
+inline int kpad_of(int k) { return K_PAD * ((k + K_PAD - 1) / K_PAD); }
 
 int check_params(const mcp_params* p) {
   if (!p) return fail(MCP_E_ARG, "params is NULL");
@@ -212,6 +214,14 @@ int mcp_launch_paths(const mcp_params* prm, const float* d_packed, uint64_t seed
   a.n_portfolios = K;
   a.compounding = prm->compounding;
   a.v0 = (float)prm->v0;
+  static const int env_mt = [] { const char* e = getenv("MCP_SWEEP_MT"); return e ? atoi(e) : 0; }();   // 0: auto, -1: off
+  if (nb <= 4 && K >= SWEEP_MIN_K && env_mt >= 0 && paths_per_thread(prm) == 1) {
+    const int mt = env_mt ? env_mt : (K > 64 ? 4 : (K > 32 ? 2 : 1));
+    a.k_begin = 0;
+    hipError_t e = mcp::launch_sweep_paths(nb, mt, (prm->flags & MCP_FLAG_NATIVE_MATH) != 0, a, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(MCP_E_NODEVICE, "mc_sweep_kernel launch: %s", hipGetErrorString(e));
+    return MCP_OK;
+  }
   for (int kb = 0; kb < K; kb += kt) {
     a.k_begin = kb;
     hipError_t e = k_launch[nb - 1](variant, a, grid, (hipStream_t)stream);

@@ -33,6 +33,8 @@ MCP_DECL_NB(1) MCP_DECL_NB(2) MCP_DECL_NB(3) MCP_DECL_NB(4) MCP_DECL_NB(5) MCP_D
 MCP_DECL_NB(9) MCP_DECL_NB(10) MCP_DECL_NB(11) MCP_DECL_NB(12) MCP_DECL_NB(13) MCP_DECL_NB(14) MCP_DECL_NB(15) MCP_DECL_NB(16)
 #undef MCP_DECL_NB
 
+// mcp_sweep_paths.hip: MFMA K-portfolio kernel (N <= 16); mt = 32-portfolio tiles per wave (1, 2 or 4)
+hipError_t launch_sweep_paths(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream);
 hipError_t launch_tables_init(float2* tables, hipStream_t s);
 hipError_t launch_moments(const mcp_params& prm, int K, const float* terminal, uint64_t stride, uint64_t n,
                           mcp_moments* partials, mcp_moments* out, hipStream_t s);

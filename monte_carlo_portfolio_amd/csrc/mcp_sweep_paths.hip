@@ -1,0 +1,144 @@
+// mcp_sweep_paths.hip -- K-portfolio path kernel on the matrix cores (BASELINE configs[4], SURVEY.md section 7
+// step 7b): all portfolios see the same normals (common random numbers), so per step the correlated
+// returns r[16 x 64 paths] of a wave are drawn ONCE and the K portfolio returns are the dense fp32 product
+//     rho[K x 64] = W[K x 16] . r[16 x 64]
+// issued as v_mfma_f32_32x32x2_f32: exact fp32, and bit for bit the k-ordered fma chain of SPEC.md section 4
+// (rho = fma(w_15, r_15, ... fma(w_0, r_0, 0))), so this kernel and mc_paths_kernel agree bitwise.
+//
+// Layout per wave: 64 paths (one per lane for the draw) x 32*MT portfolios.
+//   B operand of k-step kk for the path tile nt: lanes 0-31 carry r[2kk], lanes 32-63 carry r[2kk+1] of
+//   paths 32nt..32nt+31 -- obtained from the lane-per-path registers with ONE v_permlane32_swap per k-step
+//   (X = r[2kk], Y = r[2kk+1]: the swap exchanges X[32:63] with Y[0:31]; X becomes tile 0, Y tile 1).
+//   A operand: lane l holds W[portfolio 32mt + (l&31)][asset 2kk + (l>>5)], resident in VGPRs for all T steps.
+//   C/D: lane l, register g = portfolio 32mt + (g&3) + 8(g>>2) + 4(l>>5), path 32nt + (l&31); V is kept in
+//   the same layout for the whole walk (MT*2*16 accumulators) and compounded elementwise, V = fma(V, rho, V).
+// The W.r product is matrix-bound (2*K*16 flops per path-step); RNG and GEMV are amortised over 32*MT
+// portfolios.  N <= 16 (NB = 1..4).
+#include "mcp_paths.h"
+#include "mcp_stats_kernels.h"
+
+namespace mcp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NB, int MT, bool NATIVE>
+__global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs a) {
+  constexpr int N4 = 4 * NB, KS = N4 / 2;   // KS k-steps of 2 assets
+  typedef const __attribute__((address_space(4))) float* cfloat_p;
+  cfloat_p mu = (cfloat_p)a.packed;
+  cfloat_p Lp = mu + N4;
+  const float* __restrict__ Wg = a.packed + N4 + N4 * (N4 / 2 + 1);   // [Kpad][N4], rows >= K are zero
+
+  __shared__ float2 s_sc[BM_TAB], s_lg[BM_TAB];
+  if constexpr (!NATIVE) {
+    for (int i = threadIdx.x; i < BM_TAB; i += PATH_BLOCK) { s_sc[i] = a.tables[i]; s_lg[i] = a.tables[BM_TAB + i]; }
+    __syncthreads();
+  }
+  const PhiloxKeys ks = philox_keys((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t p = ((uint64_t)blockIdx.x * (PATH_BLOCK / 64) + wave) * 64 + lane;     // local path of this lane (draw)
+  const uint64_t g = a.path_begin + p;
+  const uint32_t plo = (uint32_t)g, phi = (uint32_t)(g >> 32);
+  const int k_base = blockIdx.y * 32 * MT;
+  const bool logc = a.compounding == MCP_COMPOUND_LOG;
+
+  float areg[MT][KS];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++)
+      areg[mt][kk] = Wg[(size_t)(k_base + 32 * mt + (lane & 31)) * N4 + 2 * kk + (lane >> 5)];
+
+  f32x16 V[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) V[mt][nt][r] = logc ? 0.0f : a.v0;
+
+  for (int t = 0; t < a.n_steps; t++) {
+    asm volatile("" : "+s"(mu), "+s"(Lp));
+    float z[N4];
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+      uint32_t x[4];
+      philox4x32_10((uint32_t)t * NB + q, 0u, plo, phi, ks, x);
+      box_muller<NATIVE>(x[0], x[1], s_sc, s_lg, z[0 * NB + q], z[1 * NB + q]);
+      box_muller<NATIVE>(x[2], x[3], s_sc, s_lg, z[2 * NB + q], z[3 * NB + q]);
+    }
+    float r[N4];
+#pragma unroll
+    for (int m = 0; m < N4 / 2; m++) {
+      f32x2 acc = {mu[2 * m], mu[2 * m + 1]};
+#pragma unroll
+      for (int j = 0; j <= 2 * m + 1; j++) {
+        const f32x2 l2 = {Lp[2 * m * (m + 1) + 2 * j], Lp[2 * m * (m + 1) + 2 * j + 1]};
+        acc = __builtin_elementwise_fma(l2, (f32x2){z[j], z[j]}, acc);
+      }
+      r[2 * m] = acc.x;
+      r[2 * m + 1] = acc.y;
+    }
+    // lane-per-path registers -> MFMA B operands of both 32-path tiles
+    float b0[KS], b1[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(r[2 * kk]), __float_as_uint(r[2 * kk + 1]), false, false);
+      b0[kk] = __uint_as_float(sw[0]);
+      b1[kk] = __uint_as_float(sw[1]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        f32x16 rho = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++)
+          rho = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[mt][kk], nt ? b1[kk] : b0[kk], rho, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+          V[mt][nt][q] = logc ? (V[mt][nt][q] + rho[q]) : fma32(V[mt][nt][q], rho[q], V[mt][nt][q]);
+      }
+    }
+  }
+
+  const uint64_t wave_path0 = ((uint64_t)blockIdx.x * (PATH_BLOCK / 64) + wave) * 64;
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+      const uint64_t path = wave_path0 + 32 * nt + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int k = k_base + 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (path < a.n_paths && k < a.n_portfolios) a.terminal[(size_t)k * a.stride + path] = V[mt][nt][q];
+      }
+    }
+}
+
+// grid.x = ceil(n_paths / 256), grid.y = ceil(K / (32 MT))
+template <int NB>
+static hipError_t go_nb(int mt, bool native, const PathArgs& args, const dim3 grid, hipStream_t stream) {
+#define MCP_GO(M, NAT) mc_sweep_kernel<NB, M, NAT><<<grid, PATH_BLOCK, 0, stream>>>(args)
+  if (mt == 1) { if (native) MCP_GO(1, true); else MCP_GO(1, false); }
+  else if (mt == 2) { if (native) MCP_GO(2, true); else MCP_GO(2, false); }
+  else if (mt == 4) { if (native) MCP_GO(4, true); else MCP_GO(4, false); }
+  else return hipErrorInvalidValue;
+#undef MCP_GO
+  return hipGetLastError();
+}
+
+hipError_t launch_sweep_paths(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream) {
+  const unsigned gx = (unsigned)((args.n_paths + PATH_BLOCK - 1) / PATH_BLOCK);
+  const unsigned gy = (unsigned)((args.n_portfolios + 32 * mt - 1) / (32 * mt));
+  const dim3 grid(gx, gy);
+  switch (nb) {
+    case 1: return go_nb<1>(mt, native, args, grid, stream);
+    case 2: return go_nb<2>(mt, native, args, grid, stream);
+    case 3: return go_nb<3>(mt, native, args, grid, stream);
+    case 4: return go_nb<4>(mt, native, args, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace mcp

@@ -207,3 +207,17 @@ def test_path_engine_two_ranks_on_one_gpu(gpu_ctx, tmp_path):
             assert float.fromhex(two[0][k][key]) == host[k][key], key
         for key in ("mean", "std", "sharpe", "cvar"):
             assert float.fromhex(two[0][k][key]) == pytest.approx(host[k][key], rel=1e-13), key
+
+
+@pytest.mark.parametrize("N,K,P,T,comp", [(16, 17, 4000, 30, "simple"), (16, 130, 3000, 25, "simple"), (16, 300, 1100, 12, "log"),
+                                          (12, 64, 2049, 20, "simple"), (3, 40, 1000, 15, "simple")])
+def test_mfma_sweep_kernel_bit_exact(gpu_ctx, N, K, P, T, comp):
+    """K >= 17, N <= 16 runs mc_sweep_kernel (W.r on v_mfma_f32_32x32x2_f32): same bits as the oracle's fma chain."""
+    got, ref = run_both(N, T, P, K=K, compounding=comp, rf=0.0005)
+    for k in range(K):
+        assert np.array_equal(got[k]["terminal"].view(np.uint32), ref[k].view(np.uint32)), k
+    for k in (0, K // 2, K - 1):
+        assert_stats(got[k], ref[k], 1.0, comp, 0.95, 0.0005, exact_quantile=(comp == "simple"))
+    sharpe = np.array([g["sharpe"] for g in got])
+    want = np.array([ref_stats.path_stats(ref[k], compounding=comp, rf=0.0005)["sharpe"] for k in range(K)])
+    assert int(np.argmax(sharpe)) == int(np.argmax(want))
