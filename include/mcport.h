@@ -166,6 +166,11 @@ int mcp_launch_tail(const mcp_params *prm, const float *d_terminal, uint64_t ter
 int mcp_launch_stats(const mcp_params *prm, const void *d_moments, const void *d_quant, const void *d_tail,
                      void *d_stats, void *stream);
 
+/* The normal generator on its own: Box-Muller (SPEC.md section 3) of n caller-supplied 32-bit pairs on the
+ * device, (xa, xb) -> (s sin, s cos).  flags: MCP_FLAG_NATIVE_MATH or 0. */
+int mcp_launch_box_muller(const uint32_t *d_xa, const uint32_t *d_xb, uint64_t n, float *d_z_sin, float *d_z_cos,
+                          int flags, void *stream);
+
 /* Host helpers shared by both levels (pure CPU). */
 uint32_t mcp_float_to_key(float v);
 float mcp_key_to_float(uint32_t key);

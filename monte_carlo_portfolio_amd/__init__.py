@@ -10,11 +10,11 @@ from .metrics import (annual_return, annual_volatility, calc_asset_stats, cvar, 
                       sortino_ratio, stats_table, var)
 from .options import (calc_option_return, calc_options_series, calculate_breakeven, calculate_payoff,  # noqa: F401
                       calculate_profit_loss_percent, strategy_rows)
-from .simulate import Context, simulate_paths  # noqa: F401
+from .simulate import Context, simulate_paths, simulate_sweep  # noqa: F401
 from .sweep import allocation, efficient_frontier, run_all_methods, run_sweep  # noqa: F401
 
 __all__ = [
-    "McpError", "build", "lib", "Context", "simulate_paths", "run_sweep", "run_all_methods", "efficient_frontier",
+    "McpError", "build", "lib", "Context", "simulate_paths", "simulate_sweep", "run_sweep", "run_all_methods", "efficient_frontier",
     "allocation", "read_csv_file", "align_prices", "load_prices", "returns_matrix", "calc_asset_stats", "stats_table",
     "sharpe_ratio", "sortino_ratio", "annual_volatility", "annual_return", "max_drawdown", "var", "cvar",
     "calc_option_return", "calc_options_series", "calculate_payoff", "calculate_breakeven",

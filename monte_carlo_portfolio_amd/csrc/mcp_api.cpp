@@ -303,6 +303,15 @@ int mcp_launch_stats(const mcp_params* prm, const void* d_moments, const void* d
   return MCP_OK;
 }
 
+int mcp_launch_box_muller(const uint32_t* d_xa, const uint32_t* d_xb, uint64_t n, float* d_zs, float* d_zc, int flags,
+                          void* stream) {
+  if (!d_xa || !d_xb || !d_zs || !d_zc) return fail(MCP_E_ARG, "NULL device pointer");
+  const float2* tables = nullptr;
+  if (int rc = device_tables((hipStream_t)stream, &tables)) return rc;
+  HIP_TRY(mcp::launch_box_muller(d_xa, d_xb, n, tables, d_zs, d_zc, (flags & MCP_FLAG_NATIVE_MATH) != 0, (hipStream_t)stream));
+  return MCP_OK;
+}
+
 uint32_t mcp_float_to_key(float v) { return mcp::float_to_key(v); }
 float mcp_key_to_float(uint32_t key) { return mcp::key_to_float(key); }
 

@@ -35,6 +35,8 @@ MCP_DECL_NB(9) MCP_DECL_NB(10) MCP_DECL_NB(11) MCP_DECL_NB(12) MCP_DECL_NB(13) M
 
 // mcp_sweep_paths.hip: MFMA K-portfolio kernel (N <= 16); mt = 32-portfolio tiles per wave (1, 2 or 4)
 hipError_t launch_sweep_paths(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream);
+hipError_t launch_box_muller(const uint32_t* xa, const uint32_t* xb, uint64_t n, const float2* tables, float* zs,
+                             float* zc, bool native, hipStream_t s);
 hipError_t launch_tables_init(float2* tables, hipStream_t s);
 hipError_t launch_moments(const mcp_params& prm, int K, const float* terminal, uint64_t stride, uint64_t n,
                           mcp_moments* partials, mcp_moments* out, hipStream_t s);

@@ -234,6 +234,35 @@ hipError_t launch_tables_init(float2* tables, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Box-Muller transform of caller-supplied 32-bit pairs (SPEC.md section 3) -- the normal generator of the
+// path kernel exposed on its own; also what tests use to hit edge inputs (u == 1, xa == 0, quadrant seams).
+template <bool NATIVE>
+__global__ void __launch_bounds__(256) box_muller_kernel(const uint32_t* __restrict__ xa, const uint32_t* __restrict__ xb,
+                                                         uint64_t n, const float2* __restrict__ tables,
+                                                         float* __restrict__ zs, float* __restrict__ zc) {
+  __shared__ float2 s_sc[BM_TAB], s_lg[BM_TAB];
+  if constexpr (!NATIVE) {
+    for (int i = threadIdx.x; i < BM_TAB; i += 256) { s_sc[i] = tables[i]; s_lg[i] = tables[BM_TAB + i]; }
+    __syncthreads();
+  }
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    float a, b;
+    box_muller<NATIVE>(xa[i], xb[i], s_sc, s_lg, a, b);
+    zs[i] = a;
+    zc[i] = b;
+  }
+}
+
+hipError_t launch_box_muller(const uint32_t* xa, const uint32_t* xb, uint64_t n, const float2* tables, float* zs,
+                             float* zc, bool native, hipStream_t s) {
+  uint64_t g = (n + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > 4096) g = 4096;
+  if (native) box_muller_kernel<true><<<(unsigned)g, 256, 0, s>>>(xa, xb, n, tables, zs, zc);
+  else box_muller_kernel<false><<<(unsigned)g, 256, 0, s>>>(xa, xb, n, tables, zs, zc);
+  return hipGetLastError();
+}
+
 __global__ void select_init_kernel(int K, uint64_t rank_lo, uint64_t rank_hi, SelectState* __restrict__ state) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * K) return;

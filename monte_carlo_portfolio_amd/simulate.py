@@ -89,21 +89,41 @@ def stats_to_dict(rec) -> dict:
 
 def simulate_paths(mu, cov, weights, n_steps=252, n_paths=10_000, seed=0, v0=1.0, compounding="simple",
                    rf=0.0, alpha=0.95, devices=None, store=False, path_begin=0, chol=None,
-                   native_math=False):
+                   native_math=False, as_array=False):
     """Simulate `n_paths` correlated return paths and reduce them to risk statistics.
 
     mu [N], cov [N,N] are per-step mean and covariance (the reference's `mean_returns`, `cov_matrix`
     of app.py:679-680 divided by `annual_factor`); weights [N] or [K,N].  Returns a dict for a single
-    weight vector or a list of dicts (plus key 'opt_idx' handled by run_sweep) for K portfolios; with
-    store=True the dict carries 'terminal' (float32 [n_paths] or [K, n_paths]).
+    weight vector or a list of dicts for K portfolios (as_array=True: the [K] record array of mcp_stats
+    instead); with store=True the dict carries 'terminal' (float32 [n_paths] or [K, n_paths]).
     """
     single = np.asarray(weights).ndim == 1
     mu32, L, W = prepare_inputs(mu, cov, weights, chol)
     prm = _ffi.make_params(mu32.shape[0], n_steps, W.shape[0], compounding, v0, alpha, rf, native_math)
     dev = 0 if not devices else int(devices[0])
     stats, term = default_context(dev).simulate(prm, mu32, L, W, int(seed), int(path_begin), int(n_paths), store)
+    if as_array:                      # [K] structured array (fields of mcp_stats), for large sweeps
+        return (stats, term) if store else stats
     out = [stats_to_dict(stats[k]) for k in range(W.shape[0])]
     if store:
         for k, d in enumerate(out):
             d["terminal"] = term[k]
     return out[0] if single else out
+
+
+def simulate_sweep(mu, cov, weights=None, n_portfolios=2500, min_weights=None, max_weights=None, n_steps=252,
+                   n_paths=100_000, seed=0, rf=0.0, alpha=0.95, method="Monte Carlo", np_seed=None, **kw):
+    """The reference's sweep (app.py:682-722) scored on SIMULATED terminal values instead of historical rows:
+    weights drawn exactly as app.py:699-707 (host, NumPy legacy RNG; pass `weights` to supply them), all
+    portfolios on common random numbers in one launch (MFMA kernel for K >= 17), metric and optimum as at
+    app.py:672-676 / 717 / 747.  -> dict(all_weights, stats [K] record array, all_metrics, opt_idx)."""
+    from .sweep import _METRIC, draw_weights, select_optimum
+    if weights is None:
+        if np_seed is not None:
+            np.random.seed(np_seed)
+        weights = draw_weights(len(np.atleast_1d(mu)), n_portfolios, min_weights, max_weights)
+    W = np.atleast_2d(np.asarray(weights, np.float64))
+    stats = simulate_paths(mu, cov, W, n_steps=n_steps, n_paths=n_paths, seed=seed, rf=rf, alpha=alpha, as_array=True, **kw)
+    metric = {"sharpe": stats["sharpe"], "var_95": -stats["var"], "cvar_95": -stats["cvar"]}[_METRIC[method]]
+    return {"all_weights": W, "stats": stats, "all_metrics": metric, "opt_idx": select_optimum(method, metric),
+            "all_risks": stats["std"], "all_returns": stats["mean"]}

@@ -221,3 +221,74 @@ def test_mfma_sweep_kernel_bit_exact(gpu_ctx, N, K, P, T, comp):
     sharpe = np.array([g["sharpe"] for g in got])
     want = np.array([ref_stats.path_stats(ref[k], compounding=comp, rf=0.0005)["sharpe"] for k in range(K)])
     assert int(np.argmax(sharpe)) == int(np.argmax(want))
+
+
+def test_config0_csv_to_simulated_stats(gpu_ctx):
+    """BASELINE configs[0] end to end: the three daily CSVs -> returns -> (mu, Sigma) -> 10k paths x 252 steps,
+    against the oracle on the same inputs (the reference itself cannot load these files)."""
+    import io, os
+    from monte_carlo_portfolio_amd import ingest
+    data = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data")
+    files = []
+    for n in ("Bitcoin Historical Data.csv", "Ethereum Historical Data.csv", "XAU_USD Historical Data.csv"):
+        b = io.BytesIO(open(os.path.join(data, n), "rb").read()); b.name = n; files.append(b)
+    names, prices, res = ingest.load_prices(files, resample_rule="D", report=lambda m: None)
+    rets = ingest.returns_matrix(res)
+    mu, cov = rets.mean().values, rets.cov().values            # per step (daily), app.py:679-680 before annualising
+    w = np.ones(3) / 3
+    got = simulate_paths(mu, cov, w, n_steps=252, n_paths=10_000, seed=SEED, store=True, v0=10000.0, rf=0.03)
+    mu32, L, W32 = prepare_inputs(mu, cov, w)
+    ref = mc_oracle.simulate(mu32, L, W32, 252, 10_000, SEED, v0=10000.0)
+    assert np.array_equal(got["terminal"].view(np.uint32), ref[0].view(np.uint32))
+    assert_stats(got, ref[0], 10000.0, "simple", 0.95, 0.03)
+
+
+def test_simulated_sweep_optimum(gpu_ctx):
+    """configs[4] shape, scaled: Dirichlet weights as the reference draws them, all on common random numbers;
+    the max-Sharpe / min-VaR indices must equal the ones computed from the oracle's terminal values."""
+    from monte_carlo_portfolio_amd import simulate_sweep
+    mu, cov = synthetic.synthetic_market(16)
+    K, P, T = 200, 4000, 40
+    out = {m: simulate_sweep(mu, cov, n_portfolios=K, n_steps=T, n_paths=P, seed=SEED, rf=0.001, method=m, np_seed=7)
+           for m in ("Monte Carlo", "VaR", "CVaR")}
+    W = out["Monte Carlo"]["all_weights"]
+    np.random.seed(7)
+    assert np.array_equal(W, np.array([np.random.dirichlet(np.ones(16), size=1)[0] for _ in range(K)]))
+    mu32, L, W32 = prepare_inputs(mu, cov, W)
+    ref = mc_oracle.simulate(mu32, L, W32, T, P, SEED)
+    st = [ref_stats.path_stats(ref[k], rf=0.001) for k in range(K)]
+    assert out["Monte Carlo"]["opt_idx"] == int(np.argmax([s["sharpe"] for s in st]))
+    assert out["VaR"]["opt_idx"] == int(np.argmin([-s["var"] for s in st]))
+    assert out["CVaR"]["opt_idx"] == int(np.argmin([-s["cvar"] for s in st]))
+    assert np.array_equal(out["VaR"]["stats"]["var"], np.array([s["var"] for s in st]))
+
+
+def test_device_box_muller_matches_oracle_everywhere(gpu_ctx):
+    """The device normal generator against the oracle's, bit for bit: edge inputs (u == 1, u minimal, every
+    table seam and quadrant seam) and 2^24 random pairs; plus the device-built tables themselves."""
+    import ctypes
+    import torch
+    L = _ffi.lib()
+    rng = np.random.default_rng(11)
+    edge = np.array([0, 1, 2, 0xffffffff, 0xfffffffe, 0xffffff7f, 0xffffff80, 0x7fffffff, 0x80000000, 0x3fffffff, 0x40000000,
+                     0x001fffff, 0x00200000, 0xffdfffff, 0xffe00000, 0xbfffffff, 0xc0000000], np.uint32)
+    seams = (np.arange(1024, dtype=np.uint32) << np.uint32(22))
+    eb = np.concatenate([edge, seams + np.uint32(0x1fffff), seams + np.uint32(0x200000), seams])
+    # xa values hitting every bin boundary of the log table: u = bin edge +- 1 ulp, mapped back through u = (xa+1) 2^-32
+    ea = np.concatenate([edge, rng.integers(0, 2 ** 32, 4000, dtype=np.uint32), (rng.integers(0, 256, 2000) + 0xffffff00).astype(np.uint32)])
+    A, B = np.meshgrid(ea[:800], eb[:800])
+    xa = np.concatenate([A.ravel(), rng.integers(0, 2 ** 32, 1 << 24, dtype=np.uint32), ea]).astype(np.uint32)
+    xb = np.concatenate([B.ravel(), rng.integers(0, 2 ** 32, 1 << 24, dtype=np.uint32), rng.integers(0, 2 ** 32, ea.size, dtype=np.uint32)]).astype(np.uint32)
+    n = xa.size
+    d_xa, d_xb = torch.from_numpy(xa.view(np.int32)).cuda(), torch.from_numpy(xb.view(np.int32)).cuda()
+    zs, zc = torch.empty(n, dtype=torch.float32, device="cuda"), torch.empty(n, dtype=torch.float32, device="cuda")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _ffi.check(L.mcp_launch_box_muller(d_xa.data_ptr(), d_xb.data_ptr(), n, zs.data_ptr(), zc.data_ptr(), 0, stream))
+    torch.cuda.synchronize()
+    ws, wc = mc_oracle.box_muller(xa, xb)
+    assert np.array_equal(zs.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+    assert np.array_equal(zc.cpu().numpy().view(np.uint32), wc.view(np.uint32))
+    # native variant: tolerance only
+    _ffi.check(L.mcp_launch_box_muller(d_xa.data_ptr(), d_xb.data_ptr(), n, zs.data_ptr(), zc.data_ptr(), 1, stream))
+    torch.cuda.synchronize()
+    assert np.max(np.abs(zs.cpu().numpy() - ws)) < 2e-5 and np.max(np.abs(zc.cpu().numpy() - wc)) < 2e-5
