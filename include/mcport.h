@@ -171,6 +171,9 @@ int mcp_launch_stats(const mcp_params *prm, const void *d_moments, const void *d
 int mcp_launch_box_muller(const uint32_t *d_xa, const uint32_t *d_xb, uint64_t n, float *d_z_sin, float *d_z_cos,
                           int flags, void *stream);
 
+/* Test hook: d_out[i] = the kernel's correctly rounded sqrt of d_in[i] (d_in in {0} U [2^-24, 64)). */
+int mcp_launch_sqrt(const float *d_in, float *d_out, uint64_t n, void *stream);
+
 /* Host helpers shared by both levels (pure CPU). */
 uint32_t mcp_float_to_key(float v);
 float mcp_key_to_float(uint32_t key);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "mcp_launch_tail": (_int, [_PP, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "mcp_launch_stats": (_int, [_PP, _vp, _vp, _vp, _vp, _vp]),
     "mcp_launch_box_muller": (_int, [_vp, _vp, _u64, _vp, _vp, _int, _vp]),
+    "mcp_launch_sqrt": (_int, [_vp, _vp, _u64, _vp]),
     "mcp_float_to_key": (ctypes.c_uint32, [ctypes.c_float]),
     "mcp_key_to_float": (ctypes.c_float, [ctypes.c_uint32]),
     "mcp_terminal_to_x": (ctypes.c_double, [_PP, ctypes.c_float]),

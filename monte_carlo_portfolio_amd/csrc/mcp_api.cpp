@@ -312,6 +312,12 @@ int mcp_launch_box_muller(const uint32_t* d_xa, const uint32_t* d_xb, uint64_t n
   return MCP_OK;
 }
 
+int mcp_launch_sqrt(const float* d_in, float* d_out, uint64_t n, void* stream) {
+  if (!d_in || !d_out) return fail(MCP_E_ARG, "NULL device pointer");
+  HIP_TRY(mcp::launch_sqrt(d_in, d_out, n, (hipStream_t)stream));
+  return MCP_OK;
+}
+
 uint32_t mcp_float_to_key(float v) { return mcp::float_to_key(v); }
 float mcp_key_to_float(uint32_t key) { return mcp::key_to_float(key); }
 

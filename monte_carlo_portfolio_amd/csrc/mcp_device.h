@@ -18,6 +18,9 @@ constexpr uint32_t PHILOX_M1 = 0xCD9E8D57u;
 constexpr uint32_t PHILOX_W0 = 0x9E3779B9u;
 constexpr uint32_t PHILOX_W1 = 0xBB67AE85u;
 
+#ifndef MCP_EXP_SQRT_NEIGHBOUR
+#define MCP_EXP_SQRT_NEIGHBOUR 1
+#endif
 #ifndef MCP_EXP_BITOP3
 #define MCP_EXP_BITOP3 1
 #endif
@@ -61,6 +64,7 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 constexpr float NEG_2LN2 = -0x1.62e43p+0f;       // -2 ln 2
 constexpr float TWO_PI_2M32 = 0x1.921fb6p-30f;   // 2 pi / 2^32
+constexpr float PI_1024 = 0x1.921fb6p-9f;        // 2^21 * TWO_PI_2M32 = pi/1024
 // sin(a) = a + a^3 S(a^2), cos(a) = 1 - a^2/2 + a^4 C(a^2) on |a| <= pi/4 (tools/fit_coeffs.py); used
 // only to BUILD the sin/cos table.
 constexpr float SS0 = -0x1.55554p-3f, SS1 = 0x1.1105b4p-7f, SS2 = -0x1.98da62p-13f;
@@ -70,9 +74,13 @@ constexpr int BM_TAB = 1024;   // entries of each Box-Muller table (float2): 8 K
 
 __device__ __forceinline__ float fma32(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
-// Correctly rounded sqrt for t in [0, 64): v_sqrt_f32 (<= 1 ulp) followed by the neighbour test LLVM
-// uses for IEEE sqrt, without the denormal pre-scaling (t is either 0 or >= 2^-24, never subnormal).
+// Correctly rounded sqrt for t in {0} U [2^-24, 64).  Default: v_sqrt_f32 (<= 1 ulp) and the two-neighbour
+// residual test LLVM uses for IEEE sqrt (no denormal pre-scaling needed in this range).  Alternative
+// (MCP_EXP_SQRT_NEIGHBOUR=0): v_rsq_f32 seed + fma refinement.  Both are checked exhaustively against sqrtf
+// over the whole range on the device (tests/test_gpu_parity.py::test_device_sqrt_is_correctly_rounded);
+// they time within 1 % of each other.
 __device__ __forceinline__ float sqrt_rn(float t) {
+#if MCP_EXP_SQRT_NEIGHBOUR
   float s = __builtin_amdgcn_sqrtf(t);
   const float s_dn = __uint_as_float(__float_as_uint(s) - 1u);
   const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
@@ -81,6 +89,17 @@ __device__ __forceinline__ float sqrt_rn(float t) {
   s = (e_dn <= 0.0f) ? s_dn : s;
   s = (e_up > 0.0f) ? s_up : s;
   return s;
+#else
+  const float y = __builtin_amdgcn_rsqf(t);          // +inf at t == 0
+  float g = t * y;                                    // ~ sqrt(t)
+  float h = y * 0.5f;
+  const float e = fma32(-h, g, 0.5f);
+  h = fma32(h, e, h);
+  g = fma32(g, e, g);
+  const float d = fma32(-g, g, t);
+  g = fma32(d, h, g);
+  return t == 0.0f ? 0.0f : g;                        // 0 * inf = NaN at t == 0
+#endif
 }
 
 // ---- table construction (SPEC.md section 3.1; run once per device by tables_init_kernel) -----------
@@ -145,10 +164,9 @@ __device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, const float
     float t = fma32((float)k, NEG_2LN2, e.y);
     t = t + w;
     const float s = sqrt_rn(t);
-    // angle: table point i = round(xb / 2^22), residual d in [-pi/1024, pi/1024): sin d ~ d, cos d ~ 1 - d^2/2
-    const float2 p = sc[(xb + 0x00200000u) >> 22];
-    const int32_t rr = (int32_t)(xb << 10) >> 10;
-    const float d = (float)rr * TWO_PI_2M32;
+    // angle: table bin i = xb >> 22 (midpoint theta_i), residual d in [-pi/1024, pi/1024): sin d ~ d, cos d ~ 1 - d^2/2
+    const float2 p = sc[xb >> 22];
+    const float d = fma32((float)(xb & 0x003fffffu), TWO_PI_2M32, -PI_1024);
     const float cd = fma32(d * -0.5f, d, 1.0f);
     const float sn = fma32(p.y, d, p.x * cd);
     const float cs = fma32(-p.x, d, p.y * cd);

@@ -219,12 +219,12 @@ __global__ void stats_kernel(const mcp_params prm, int K, const mcp_moments* __r
   out[k] = s;
 }
 
-// Box-Muller tables (SPEC.md section 3.1): tables[0..1023] = (sin, cos)(2 pi i/1024), tables[1024..2047] = log table.
+// Box-Muller tables (SPEC.md section 3.1): tables[0..1023] = (sin, cos)(2 pi (i + 1/2)/1024), tables[1024..2047] = log table.
 __global__ void __launch_bounds__(256) tables_init_kernel(float2* __restrict__ tables) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (uint32_t)BM_TAB) return;
   float sn, cs;
-  sincos_poly(i << 22, sn, cs);
+  sincos_poly((i << 22) + 0x00200000u, sn, cs);
   tables[i] = make_float2(sn, cs);
   tables[BM_TAB + i] = log_table_entry(i);
 }
@@ -260,6 +260,15 @@ hipError_t launch_box_muller(const uint32_t* xa, const uint32_t* xb, uint64_t n,
   if (g > 4096) g = 4096;
   if (native) box_muller_kernel<true><<<(unsigned)g, 256, 0, s>>>(xa, xb, n, tables, zs, zc);
   else box_muller_kernel<false><<<(unsigned)g, 256, 0, s>>>(xa, xb, n, tables, zs, zc);
+  return hipGetLastError();
+}
+
+// out[i] = sqrt_rn(in[i]) -- test hook for the exhaustive correct-rounding check of the device sqrt.
+__global__ void __launch_bounds__(256) sqrt_kernel(const float* __restrict__ in, float* __restrict__ out, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) out[i] = sqrt_rn(in[i]);
+}
+hipError_t launch_sqrt(const float* in, float* out, uint64_t n, hipStream_t s) {
+  sqrt_kernel<<<4096, 256, 0, s>>>(in, out, n);
   return hipGetLastError();
 }
 

@@ -66,13 +66,14 @@ MCO_INLINE uint32_t f32_as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return 
 
 /* ---- Box-Muller pair, SPEC.md section 3: table-driven, exact arithmetic ------------------------
  * Two 1024-entry tables (on the GPU they live in LDS):
- *   SC[i] = (sin, cos)(2 pi i / 1024)            built with the fixed fp32 polynomial below
+ *   SC[i] = (sin, cos)(2 pi (i + 1/2) / 1024)    built with the fixed fp32 polynomial below (bin midpoints)
  *   LG[j] = (inv_c, -2 ln(1/inv_c))               c = midpoint of mantissa bin j of [sqrt(.5), sqrt(2)),
  *                                                 the bin holding 1.0 uses c = 1 exactly
  * Table construction uses only IEEE +,*,/,fma (binary32 and binary64), so it is reproducible
  * bit for bit on any IEEE machine; the HIP side builds the same tables in a device init kernel.  */
 #define NEG_2LN2 -0x1.62e43p+0f          /* -2 ln 2 rounded to binary32 */
 #define TWO_PI_2M32 0x1.921fb6p-30f      /* 2 pi / 2^32 rounded to binary32 */
+#define PI_1024 0x1.921fb6p-9f           /* 2^21 * TWO_PI_2M32 = pi/1024 (same significand) */
 /* sin(a) = a + a^3 S(a^2), cos(a) = 1 - a^2/2 + a^4 C(a^2), |a| <= pi/4 (tools/fit_coeffs.py) */
 #define SS0 -0x1.55554p-3f
 #define SS1  0x1.1105b4p-7f
@@ -115,7 +116,7 @@ static double ln_series(double x)
 
 static void build_tables(void)
 {
-    for (uint32_t i = 0; i < MCO_TAB; i++) sincos_poly(i << 22, &g_sc[i][0], &g_sc[i][1]);
+    for (uint32_t i = 0; i < MCO_TAB; i++) sincos_poly((i << 22) + 0x00200000u, &g_sc[i][0], &g_sc[i][1]);
     for (uint32_t j = 0; j < MCO_TAB; j++) {
         uint32_t lo = 0x3f3504f3u + (j << 13);
         float c = u32_as_f32(lo + 0x1000u);
@@ -148,10 +149,9 @@ MCO_INLINE void box_muller(uint32_t xa, uint32_t xb, float *z_sin, float *z_cos)
     float t = fmaf((float)k, NEG_2LN2, g_lg[j][1]);
     t = t + w;
     float s = sqrtf(t);
-    /* angle: theta = 2 pi xb / 2^32 = theta_i + d, table point i, |d| <= pi/1024 */
-    uint32_t i = (xb + 0x00200000u) >> 22;
-    int32_t rr = (int32_t)(xb << 10) >> 10;                  /* xb - i*2^22, in [-2^21, 2^21) */
-    float d = (float)rr * TWO_PI_2M32;
+    /* angle: theta = 2 pi xb / 2^32 = theta_i + d, theta_i = midpoint of table bin i = xb >> 22, |d| <= pi/1024 */
+    uint32_t i = xb >> 22;
+    float d = fmaf((float)(xb & 0x003fffffu), TWO_PI_2M32, -PI_1024);   /* (xb mod 2^22 - 2^21) 2 pi / 2^32 */
     float sc = g_sc[i][0], cc = g_sc[i][1];
     float cd = fmaf(d * -0.5f, d, 1.0f);                     /* cos d */
     float sn = fmaf(cc, d, sc * cd);                         /* sin(theta_i + d), sin d ~ d */
