@@ -10,7 +10,9 @@ A "step" is one full pass of the hot path over one batch resident in HBM: fused 
 (Philox -> Box-Muller -> Cholesky GEMV -> compounding) for BASELINE configs[1] per GPU (16 synthetic
 assets, 1,000,000 paths, 252 steps, fp32), then moments, exact VaR (3-pass radix select) and CVaR,
 with the cross-rank exchanges of SURVEY.md section 8(e) when N > 1.  Weak scaling: every rank simulates its
-own 1M-path shard of one global path range.
+own 1M-path shard of one global path range.  Steps are independent batches; PathEngine double-buffers them
+over HIP streams (the statistics passes and collectives of batch i overlap the path kernel of batch i+1), and
+the timed region ends with a barrier + device synchronise, so every batch is complete inside it.
 """
 import argparse
 import json
@@ -177,7 +179,8 @@ def main():
                                    "full pass = paths + moments + exact VaR/CVaR",
                        "n_assets": N_ASSETS, "n_steps": N_STEPS, "paths_per_gpu": PATHS_PER_GPU,
                        "global_paths": PATHS_PER_GPU * world, "parallelism": f"path-sharded x{world}",
-                       "math": "native" if args.native_math else "exact"},
+                       "math": "native" if args.native_math else "exact",
+                       "pipeline": "double-buffered batches: path kernel i+1 overlaps statistics + collectives of batch i"},
             "stats": {"mean": float(stats["mean"]), "std": float(stats["std"]), "sharpe": float(stats["sharpe"]),
                       "var95": float(stats["var"]), "cvar95": float(stats["cvar"]), "n": int(stats["n"]),
                       "n_tail": int(stats["n_tail"])},

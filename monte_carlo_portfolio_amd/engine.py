@@ -75,8 +75,14 @@ class HipKernels:
 
 
 class PathEngine:
+    """One rank's pipeline.  `step()` enqueues one full pass; with `pipeline=True` (default on a GPU) passes
+    are double-buffered over two HIP streams: the statistics passes and the collectives of batch i run on
+    the statistics stream while the path kernel of batch i+1 already runs on the path stream, so the
+    latency-bound tail of a pass (16 small launches, 5 collectives) is hidden behind VALU-bound work."""
+
     def __init__(self, mu32, chol32, W32, n_steps, n_paths_local, *, compounding="simple", v0=1.0, alpha=0.95,
-                 rf=0.0, native_math=False, device=None, group=None, world_size=1, rank=0, kernels=None):
+                 rf=0.0, native_math=False, device=None, group=None, world_size=1, rank=0, kernels=None,
+                 pipeline=True):
         import torch
 
         self.torch = torch
@@ -92,56 +98,116 @@ class PathEngine:
         self.K = K
         self.prm = _ffi.make_params(mu32.shape[0], n_steps, K, compounding, v0, alpha, rf, native_math)
         self.rank_lo, self.rank_hi, self.gamma = _ffi.percentile_rank(self.n_total, alpha)
+        self.pipeline = bool(pipeline) and self.device.type == "cuda"
+        self.n_buf = 2 if self.pipeline else 1
 
         lib = _ffi.lib()
         packed = _ffi.pack_params(mu32, chol32, W32)
         self.d_packed = torch.from_numpy(packed).to(self.device)
-        self.d_terminal = torch.empty((K, self.n_local), dtype=torch.float32, device=self.device)
-        self.ws = {}
-        for which in range(8):
-            nbytes = lib.mcp_ws_bytes(which, K)
-            self.ws[which] = torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=self.device)
-        # typed views for the collectives
-        self.moments = self.ws[_ffi.WS_MOMENTS].view(torch.float64).view(K, 5)
-        self.hist = self.ws[_ffi.WS_HIST]                                  # int64 counts [K][2][2048]
-        self.tail = self.ws[_ffi.WS_TAIL].view(torch.float64).view(K, 2)
-        if self.world > 1:
-            self._gather = torch.empty((self.world * K, 5), dtype=torch.float64, device=self.device)
+        self.bufs = []
+        for _ in range(self.n_buf):
+            b = {"terminal": torch.empty((K, self.n_local), dtype=torch.float32, device=self.device), "ws": {}}
+            for which in range(8):
+                nbytes = lib.mcp_ws_bytes(which, K)
+                b["ws"][which] = torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=self.device)
+            # typed views for the collectives
+            b["moments"] = b["ws"][_ffi.WS_MOMENTS].view(torch.float64).view(K, 5)
+            b["hist"] = b["ws"][_ffi.WS_HIST]                                  # int64 counts [K][2][2048]
+            b["tail"] = b["ws"][_ffi.WS_TAIL].view(torch.float64).view(K, 2)
+            if self.world > 1:
+                b["gather"] = torch.empty((self.world * K, 5), dtype=torch.float64, device=self.device)
+            self.bufs.append(b)
+        self.cur = 0                                   # buffer the NEXT step writes
+        self.last = 0                                  # buffer of the most recent step
+        if self.pipeline:
+            # one path stream per buffer: the next batch's path kernel fills the CUs that the previous one's
+            # last (partial) round of waves leaves idle
+            self.s_paths = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+            self.s_stats = torch.cuda.Stream(self.device)
+            self.ev_paths = [torch.cuda.Event() for _ in range(2)]
+            self.ev_stats = [torch.cuda.Event() for _ in range(2)]
+            for e in self.ev_stats:
+                e.record(torch.cuda.current_stream(self.device))
+            # buffers were filled on the current stream: order both pipeline streams after it
+            for sp in self.s_paths:
+                sp.wait_stream(torch.cuda.current_stream(self.device))
+            self.s_stats.wait_stream(torch.cuda.current_stream(self.device))
 
-    def step(self, seed: int, path_base: int = 0):
-        """Enqueue one full pass (paths -> statistics) on the current stream.  No host sync."""
-        k, K, n, ws = self.k, self.K, self.n_local, self.ws
+    # convenience views of the most recent step's buffers
+    @property
+    def d_terminal(self):
+        return self.bufs[self.last]["terminal"]
+
+    @property
+    def ws(self):
+        return self.bufs[self.last]["ws"]
+
+    def _enqueue_paths(self, b, seed, path_base):
+        n = self.n_local
+        self.k.paths(self.prm, self.d_packed, seed, path_base + self.rank * n, n, b["terminal"])
+
+    def _enqueue_stats(self, b):
+        k, K, n, ws = self.k, self.K, self.n_local, b["ws"]
         dist = self.torch.distributed if self.world > 1 else None
-        k.paths(self.prm, self.d_packed, seed, path_base + self.rank * n, n, self.d_terminal)
-        k.moments(self.prm, self.d_terminal, n, ws[_ffi.WS_PARTIALS], ws[_ffi.WS_MOMENTS])
+        k.moments(self.prm, b["terminal"], n, ws[_ffi.WS_PARTIALS], ws[_ffi.WS_MOMENTS])
         if dist is not None:
-            dist.all_gather_into_tensor(self._gather, self.moments, group=self.group)
-            g = self._gather.view(self.world, K, 5)
-            self.moments[:, 0:3] = g[:, :, 0:3].sum(dim=0)
-            self.moments[:, 3] = g[:, :, 3].amin(dim=0)
-            self.moments[:, 4] = g[:, :, 4].amax(dim=0)
+            dist.all_gather_into_tensor(b["gather"], b["moments"], group=self.group)
+            g = b["gather"].view(self.world, K, 5)
+            b["moments"][:, 0:3] = g[:, :, 0:3].sum(dim=0)
+            b["moments"][:, 3] = g[:, :, 3].amin(dim=0)
+            b["moments"][:, 4] = g[:, :, 4].amax(dim=0)
         k.select_init(K, self.rank_lo, self.rank_hi, ws[_ffi.WS_STATE])
         for p in range(3):
-            k.select_hist(K, self.d_terminal, n, p, ws[_ffi.WS_STATE], ws[_ffi.WS_HIST])
+            k.select_hist(K, b["terminal"], n, p, ws[_ffi.WS_STATE], ws[_ffi.WS_HIST])
             if dist is not None:
-                dist.all_reduce(self.hist, group=self.group)
+                dist.all_reduce(b["hist"], group=self.group)
             k.select_scan(K, p, ws[_ffi.WS_HIST], ws[_ffi.WS_STATE])
         k.quantile(self.prm, self.gamma, ws[_ffi.WS_STATE], ws[_ffi.WS_QUANT])
-        k.tail(self.prm, self.d_terminal, n, ws[_ffi.WS_QUANT], ws[_ffi.WS_TAIL_PARTIAL], ws[_ffi.WS_TAIL])
+        k.tail(self.prm, b["terminal"], n, ws[_ffi.WS_QUANT], ws[_ffi.WS_TAIL_PARTIAL], ws[_ffi.WS_TAIL])
         if dist is not None:
-            dist.all_reduce(self.tail, group=self.group)
+            dist.all_reduce(b["tail"], group=self.group)
         k.stats(self.prm, ws[_ffi.WS_MOMENTS], ws[_ffi.WS_QUANT], ws[_ffi.WS_TAIL], ws[_ffi.WS_STATS])
 
+    def step(self, seed: int, path_base: int = 0):
+        """Enqueue one full pass (paths -> statistics).  No host sync."""
+        i = self.cur
+        b = self.bufs[i]
+        if not self.pipeline:
+            self._enqueue_paths(b, seed, path_base)
+            self._enqueue_stats(b)
+        else:
+            torch = self.torch
+            sp = self.s_paths[i]
+            with torch.cuda.stream(sp):
+                sp.wait_event(self.ev_stats[i])                 # the pass that last used this buffer is done
+                self._enqueue_paths(b, seed, path_base)
+                self.ev_paths[i].record(sp)
+            with torch.cuda.stream(self.s_stats):
+                self.s_stats.wait_event(self.ev_paths[i])
+                self._enqueue_stats(b)
+                self.ev_stats[i].record(self.s_stats)
+        self.last = i
+        self.cur = (i + 1) % self.n_buf
+
     def launch_paths_only(self, seed: int, path_base: int = 0):
-        """The dominant kernel alone (roofline timing)."""
-        n = self.n_local
-        self.k.paths(self.prm, self.d_packed, seed, path_base + self.rank * n, n, self.d_terminal)
+        """The dominant kernel alone, on the current stream (roofline timing)."""
+        self._enqueue_paths(self.bufs[self.last], seed, path_base)
+
+    def synchronize(self):
+        if self.pipeline:
+            for sp in self.s_paths:
+                sp.synchronize()
+            self.s_stats.synchronize()
+        elif self.device.type == "cuda":
+            self.torch.cuda.synchronize(self.device)
 
     def stats(self) -> np.ndarray:
         """Synchronise and fetch the [K] mcp_stats records of the last step()."""
+        self.synchronize()
         nbytes = self.K * _ffi.STATS_DTYPE.itemsize
         raw = self.ws[_ffi.WS_STATS].cpu().numpy().view(np.uint8)[:nbytes]
         return raw.view(_ffi.STATS_DTYPE).copy()
 
     def terminal(self) -> np.ndarray:
+        self.synchronize()
         return self.d_terminal.cpu().numpy()
