@@ -38,7 +38,7 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 constexpr int KT_WIDE = 8;           // portfolios per pass of the KT=8 kernel
-constexpr int K_PAD = 128;           // W rows are zero-padded to a multiple of this (MFMA sweep tile: 32*MT)
+constexpr int K_PAD = 512;           // W rows are zero-padded to a multiple of this (MFMA sweep tile: 32*MT)
 constexpr int SWEEP_MIN_K = 17;      // from this many portfolios on (and N <= 16) the MFMA sweep kernel runs
 constexpr int GRID_CAP = 8192;       // path-kernel blocks; tiles beyond are grid-strided
 
@@ -217,8 +217,12 @@ int mcp_launch_paths(const mcp_params* prm, const float* d_packed, uint64_t seed
   static const int env_mt = [] { const char* e = getenv("MCP_SWEEP_MT"); return e ? atoi(e) : 0; }();   // 0: auto, -1: off
   if (nb <= 4 && K >= SWEEP_MIN_K && env_mt >= 0 && paths_per_thread(prm) == 1) {
     const int mt = env_mt ? env_mt : (K > 64 ? 4 : (K > 32 ? 2 : 1));
+    const bool native = (prm->flags & MCP_FLAG_NATIVE_MATH) != 0;
+    static const int env_shared = [] { const char* e = getenv("MCP_SWEEP_SHARED"); return e ? atoi(e) : 1; }();
     a.k_begin = 0;
-    hipError_t e = mcp::launch_sweep_paths(nb, mt, (prm->flags & MCP_FLAG_NATIVE_MATH) != 0, a, (hipStream_t)stream);
+    // >= 384 portfolios: four waves share one draw per 64 paths (512-portfolio workgroups)
+    hipError_t e = (K >= 384 && env_shared && !env_mt) ? mcp::launch_sweep_shared(nb, native, a, (hipStream_t)stream)
+                                                      : mcp::launch_sweep_paths(nb, mt, native, a, (hipStream_t)stream);
     if (e != hipSuccess) return fail(MCP_E_NODEVICE, "mc_sweep_kernel launch: %s", hipGetErrorString(e));
     return MCP_OK;
   }

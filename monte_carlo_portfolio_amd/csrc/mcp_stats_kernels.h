@@ -34,6 +34,7 @@ MCP_DECL_NB(9) MCP_DECL_NB(10) MCP_DECL_NB(11) MCP_DECL_NB(12) MCP_DECL_NB(13) M
 #undef MCP_DECL_NB
 
 // mcp_sweep_paths.hip: MFMA K-portfolio kernel (N <= 16); mt = 32-portfolio tiles per wave (1, 2 or 4)
+hipError_t launch_sweep_shared(int nb, bool native, const PathArgs& args, hipStream_t stream);
 hipError_t launch_sweep_paths(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream);
 hipError_t launch_box_muller(const uint32_t* xa, const uint32_t* xb, uint64_t n, const float2* tables, float* zs,
                              float* zc, bool native, hipStream_t s);

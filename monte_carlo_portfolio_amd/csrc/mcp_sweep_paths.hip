@@ -116,6 +116,142 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
     }
 }
 
+// ---- shared-draw variant: the four waves of a workgroup own the SAME 64 paths and 4 x 128 = 512 portfolios.
+// The per-step draw is split four ways and exchanged through LDS: wave w runs Philox blocks q = w, w+4, ...
+// and its Box-Muller pairs (z rows to LDS), then row pairs m = w, w+4, ... of the GEMV (r rows to LDS); after
+// the second barrier every wave reads its MFMA B operands straight from the r image (lane l: r[2kk + (l>>5)]
+// [32nt + (l&31)], conflict-free), so no permlane is needed.  Two barriers per step, z/r double-buffered by the
+// parity of t.  Same arithmetic, same order: bit-identical to mc_sweep_kernel and to the oracle.
+template <int NB, bool NATIVE>
+__global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const PathArgs a) {
+  constexpr int N4 = 4 * NB, KS = N4 / 2, MT = 4;
+  typedef const __attribute__((address_space(4))) float* cfloat_p;
+  cfloat_p mu = (cfloat_p)a.packed;
+  cfloat_p Lp = mu + N4;
+  const float* __restrict__ Wg = a.packed + N4 + N4 * (N4 / 2 + 1);
+
+  __shared__ float2 s_sc[BM_TAB], s_lg[BM_TAB];
+  __shared__ float s_z[2][N4][64], s_r[2][N4][64];
+  if constexpr (!NATIVE) {
+    for (int i = threadIdx.x; i < BM_TAB; i += PATH_BLOCK) { s_sc[i] = a.tables[i]; s_lg[i] = a.tables[BM_TAB + i]; }
+  }
+  __syncthreads();
+  const PhiloxKeys ks = philox_keys((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t p = (uint64_t)blockIdx.x * 64 + lane;             // all four waves: the same 64 paths
+  const uint64_t g = a.path_begin + p;
+  const uint32_t plo = (uint32_t)g, phi = (uint32_t)(g >> 32);
+  const int k_base = (blockIdx.y * 4 + wave) * 32 * MT;
+  const bool logc = a.compounding == MCP_COMPOUND_LOG;
+
+  float areg[MT][KS];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++)
+      areg[mt][kk] = Wg[(size_t)(k_base + 32 * mt + (lane & 31)) * N4 + 2 * kk + (lane >> 5)];
+
+  f32x16 V[MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) V[mt][nt][r] = logc ? 0.0f : a.v0;
+
+  for (int t = 0; t < a.n_steps; t++) {
+    asm volatile("" : "+s"(mu), "+s"(Lp));
+    const int buf = t & 1;
+    // phase A: this wave's share of the normals
+#pragma unroll
+    for (int q0 = 0; q0 < NB; q0 += 4) {
+      const int q = q0 + wave;                                      // wave-uniform
+      if (q < NB) {
+        uint32_t x[4];
+        philox4x32_10((uint32_t)t * NB + q, 0u, plo, phi, ks, x);
+        float z0, z1, z2, z3;
+        box_muller<NATIVE>(x[0], x[1], s_sc, s_lg, z0, z1);
+        box_muller<NATIVE>(x[2], x[3], s_sc, s_lg, z2, z3);
+        s_z[buf][0 * NB + q][lane] = z0;
+        s_z[buf][1 * NB + q][lane] = z1;
+        s_z[buf][2 * NB + q][lane] = z2;
+        s_z[buf][3 * NB + q][lane] = z3;
+      }
+    }
+    __syncthreads();
+    // phase B: this wave's row pairs of r = mu + L z
+#pragma unroll
+    for (int m0 = 0; m0 < N4 / 2; m0 += 4) {
+#pragma unroll
+      for (int wv = 0; wv < 4; wv++) {                              // unrolled so that m is a compile-time constant
+        const int m = m0 + wv;
+        if (m < N4 / 2 && wv == wave) {
+          f32x2 acc = {mu[2 * m], mu[2 * m + 1]};
+#pragma unroll
+          for (int j = 0; j <= 2 * m + 1; j++) {
+            const f32x2 l2 = {Lp[2 * m * (m + 1) + 2 * j], Lp[2 * m * (m + 1) + 2 * j + 1]};
+            const float zj = s_z[buf][j][lane];
+            acc = __builtin_elementwise_fma(l2, (f32x2){zj, zj}, acc);
+          }
+          s_r[buf][2 * m][lane] = acc.x;
+          s_r[buf][2 * m + 1][lane] = acc.y;
+        }
+      }
+    }
+    __syncthreads();
+    // phase C: rho = W . r on the matrix cores, then compounding
+    float b[2][KS];
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++) b[nt][kk] = s_r[buf][2 * kk + (lane >> 5)][32 * nt + (lane & 31)];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+      for (int nt = 0; nt < 2; nt++) {
+        f32x16 rho = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++) rho = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[mt][kk], b[nt][kk], rho, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+          V[mt][nt][q] = logc ? (V[mt][nt][q] + rho[q]) : fma32(V[mt][nt][q], rho[q], V[mt][nt][q]);
+      }
+    }
+  }
+
+  const uint64_t path0 = (uint64_t)blockIdx.x * 64;
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+      const uint64_t path = path0 + 32 * nt + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int k = k_base + 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        if (path < a.n_paths && k < a.n_portfolios) a.terminal[(size_t)k * a.stride + path] = V[mt][nt][q];
+      }
+    }
+}
+
+template <int NB>
+static hipError_t go_shared(bool native, const PathArgs& args, hipStream_t stream) {
+  const dim3 grid((unsigned)((args.n_paths + 63) / 64), (unsigned)((args.n_portfolios + 511) / 512));
+  if (native) mc_sweep_shared_kernel<NB, true><<<grid, PATH_BLOCK, 0, stream>>>(args);
+  else mc_sweep_shared_kernel<NB, false><<<grid, PATH_BLOCK, 0, stream>>>(args);
+  return hipGetLastError();
+}
+
+// K rows of W must be zero-padded to a multiple of 512 (mcp_pack_params pads to K_PAD).
+hipError_t launch_sweep_shared(int nb, bool native, const PathArgs& args, hipStream_t stream) {
+  switch (nb) {
+    case 1: return go_shared<1>(native, args, stream);
+    case 2: return go_shared<2>(native, args, stream);
+    case 3: return go_shared<3>(native, args, stream);
+    case 4: return go_shared<4>(native, args, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 // grid.x = ceil(n_paths / 256), grid.y = ceil(K / (32 MT))
 template <int NB>
 static hipError_t go_nb(int mt, bool native, const PathArgs& args, const dim3 grid, hipStream_t stream) {

@@ -50,7 +50,7 @@ def test_pack_params_layout(mcp_lib):
     W = rng.normal(size=(K, N)).astype(np.float32)
     p = _ffi.pack_params(mu, L, W)
     n4 = 8
-    assert p.size == n4 + n4 * (n4 // 2 + 1) + 128 * n4 == mcp_lib.mcp_packed_len(N, K)
+    assert p.size == n4 + n4 * (n4 // 2 + 1) + 512 * n4 == mcp_lib.mcp_packed_len(N, K)
     assert np.array_equal(p[:N], mu) and not np.signbit(p[2]) and np.all(p[N:n4] == 0)
     Lp = p[n4:n4 + n4 * (n4 // 2 + 1)]
     for m in range(n4 // 2):                      # row pairs (2m, 2m+1), columns interleaved
@@ -59,7 +59,7 @@ def test_pack_params_layout(mcp_lib):
                 i = 2 * m + h
                 want = L[i, j] if (i < N and j <= i) else 0.0
                 assert Lp[2 * m * (m + 1) + 2 * j + h] == want
-    Wp = p[n4 + n4 * (n4 // 2 + 1):].reshape(128, n4)
+    Wp = p[n4 + n4 * (n4 // 2 + 1):].reshape(512, n4)
     assert np.array_equal(Wp[:K, :N], W) and np.all(Wp[:K, N:] == 0) and np.all(Wp[K:] == 0)
 
 

@@ -210,7 +210,9 @@ def test_path_engine_two_ranks_on_one_gpu(gpu_ctx, tmp_path):
 
 
 @pytest.mark.parametrize("N,K,P,T,comp", [(16, 17, 4000, 30, "simple"), (16, 130, 3000, 25, "simple"), (16, 300, 1100, 12, "log"),
-                                          (12, 64, 2049, 20, "simple"), (3, 40, 1000, 15, "simple")])
+                                          (12, 64, 2049, 20, "simple"), (3, 40, 1000, 15, "simple"),
+                                          (16, 384, 300, 10, "simple"), (16, 700, 257, 8, "log"), (10, 513, 130, 6, "simple"),
+                                          (4, 400, 100, 9, "simple")])
 def test_mfma_sweep_kernel_bit_exact(gpu_ctx, N, K, P, T, comp):
     """K >= 17, N <= 16 runs mc_sweep_kernel (W.r on v_mfma_f32_32x32x2_f32): same bits as the oracle's fma chain."""
     got, ref = run_both(N, T, P, K=K, compounding=comp, rf=0.0005)
@@ -344,3 +346,38 @@ def test_pipelined_engine_batches_are_independent_and_correct(gpu_ctx):
     plain = PathEngine(mu32, L, W32, T, P, pipeline=False)
     plain.step(seeds[-1])
     assert plain.stats()[0] == eng.stats()[0]
+
+
+def test_config3_shape_64_assets_1260_steps(gpu_ctx):
+    """BASELINE configs[3] shape (64 assets, 1260 steps) on 20k paths: first 1,500 paths bit-exact against the
+    oracle, the rest through size-independent properties (partition invariance, analytic mean)."""
+    N, T, P = 64, 1260, 20_000
+    mu, cov = synthetic.synthetic_market(N)
+    w = synthetic.equal_weights(N)
+    r = simulate_paths(mu, cov, w, n_steps=T, n_paths=P, seed=SEED, store=True)
+    mu32, L, W32 = prepare_inputs(mu, cov, w)
+    ref = mc_oracle.simulate(mu32, L, W32, T, 1500, SEED)
+    assert np.array_equal(r["terminal"][:1500].view(np.uint32), ref[0].view(np.uint32))
+    tail = simulate_paths(mu, cov, w, n_steps=T, n_paths=5000, seed=SEED, store=True, path_begin=15_000)["terminal"]
+    assert np.array_equal(tail, r["terminal"][15_000:])
+    analytic = (1.0 + float(w @ mu)) ** T - 1.0
+    assert abs(r["mean"] - analytic) < 5 * r["std"] / np.sqrt(P)
+    x = r["terminal"].astype(np.float64) - 1.0
+    assert r["var"] == np.percentile(x, (1 - 0.95) * 100) and r["n_tail"] == int((x <= r["var"]).sum())
+
+
+def test_config2_shard_scale_properties(gpu_ctx):
+    """BASELINE configs[2]: 100M paths over 8 GPUs = 12.5M per GPU.  One shard at full size: moments and order
+    statistics against NumPy on the downloaded values, and consistency of two half-shards with the whole."""
+    N, T, P = 16, 252, 12_500_000
+    mu, cov = synthetic.synthetic_market(N)
+    w = synthetic.equal_weights(N)
+    r = simulate_paths(mu, cov, w, n_steps=T, n_paths=P, seed=SEED, store=True, path_begin=3 * P)
+    x = r["terminal"].astype(np.float64) - 1.0
+    assert r["n"] == P and r["var"] == np.percentile(x, (1 - 0.95) * 100)
+    assert r["n_tail"] == int((x <= r["var"]).sum()) == 625_000
+    assert r["mean"] == pytest.approx(x.mean(), rel=1e-12) and r["std"] == pytest.approx(x.std(ddof=1), rel=1e-11)
+    assert r["min"] == x.min() and r["max"] == x.max()
+    mu32, L, W32 = prepare_inputs(mu, cov, w)
+    ref = mc_oracle.simulate(mu32, L, W32, T, 4096, SEED, path_begin=3 * P + P - 4096)      # the shard's last paths
+    assert np.array_equal(r["terminal"][-4096:].view(np.uint32), ref[0].view(np.uint32))

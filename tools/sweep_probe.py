@@ -9,7 +9,7 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
 mu, cov = synthetic.synthetic_market(16)
 mu32, L, W32 = prepare_inputs(mu, cov, synthetic.dirichlet_weights(16, K))
-eng = PathEngine(mu32, L, W32, 252, P)
+eng = PathEngine(mu32, L, W32, 252, P, pipeline=False)
 for name, fn in (("paths", eng.launch_paths_only), ("full", eng.step)):
     fn(1); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
