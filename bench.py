@@ -63,6 +63,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--native-math", action="store_true", help="hardware log/sqrt/sin/cos Box-Muller (tolerance parity)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", action="store_true",
+                    help="side benchmark, NOT the BASELINE metric: configs[4] shape (10,000 Dirichlet portfolios, 16 assets, "
+                         "252 steps, --sweep-paths paths), portfolio-sharded over the ranks, MFMA kernel")
+    ap.add_argument("--sweep-paths", type=int, default=131072)
     args = ap.parse_args()
 
     import torch
@@ -86,9 +90,37 @@ def main():
     from monte_carlo_portfolio_amd.simulate import prepare_inputs
 
     mu, cov = synthetic.synthetic_market(N_ASSETS)
+    seed = synthetic.BENCH_SEED
+    if args.sweep:
+        K = 10_000
+        mu32, L, W32 = prepare_inputs(mu, cov, synthetic.dirichlet_weights(N_ASSETS, K))
+        eng = PathEngine(mu32, L, W32, N_STEPS, args.sweep_paths, group=group, world_size=world, rank=rank,
+                         native_math=args.native_math, shard="portfolios", pipeline=False)
+        for _ in range(max(args.warmup, 1)):
+            eng.step(seed)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.step(seed)
+        st = eng.gathered_stats()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        if rank == 0:
+            flops = 2.0 * K * N_ASSETS * args.sweep_paths * N_STEPS
+            print(json.dumps({"metric": "portfolio-paths/s (side benchmark, configs[4] shape)", "value": K * args.sweep_paths / dt,
+                              "unit": "portfolio-paths/s", "n_gpus": world, "steps": args.steps, "ms_per_step": dt * 1e3,
+                              "config": {"workload": f"10,000 portfolios x {args.sweep_paths} paths x 252 steps, 16 assets, portfolio-sharded"},
+                              "wr_product_tflops": flops / dt / 1e12, "opt_idx_max_sharpe": int(np.argmax(st["sharpe"])),
+                              "configs4_seconds_extrapolated": dt * 1e6 / args.sweep_paths}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     w = synthetic.equal_weights(N_ASSETS)
     mu32, L, W32 = prepare_inputs(mu, cov, w)
-    seed = synthetic.BENCH_SEED
     eng = PathEngine(mu32, L, W32, N_STEPS, PATHS_PER_GPU, group=group, world_size=world, rank=rank,
                      native_math=args.native_math)
 

@@ -82,7 +82,7 @@ class PathEngine:
 
     def __init__(self, mu32, chol32, W32, n_steps, n_paths_local, *, compounding="simple", v0=1.0, alpha=0.95,
                  rf=0.0, native_math=False, device=None, group=None, world_size=1, rank=0, kernels=None,
-                 pipeline=True):
+                 pipeline=True, shard="paths"):
         import torch
 
         self.torch = torch
@@ -91,6 +91,20 @@ class PathEngine:
             kernels = HipKernels(torch, device)
         self.k = kernels
         self.device = torch.device(device if device is not None else kernels.device_type)
+        if shard not in ("paths", "portfolios"):
+            raise ValueError("shard must be 'paths' or 'portfolios'")
+        self.shard = shard
+        self.gather_group, self.gather_world, self.gather_rank = group, int(world_size), int(rank)
+        if shard == "portfolios":
+            # BASELINE configs[4]: every rank walks ALL paths for its own slice of the weight matrix (same seed ->
+            # common random numbers across ranks); no data-path collective at all, one all_gather of the records.
+            k_all = W32.shape[0]
+            kc = -(-k_all // int(world_size))
+            self.k_slice = (min(int(rank) * kc, k_all), min((int(rank) + 1) * kc, k_all))
+            self.k_chunk, self.k_all = kc, k_all
+            W_local = np.zeros((kc, W32.shape[1]), np.float32)           # ragged last rank: zero-weight padding rows
+            W_local[:self.k_slice[1] - self.k_slice[0]] = W32[self.k_slice[0]:self.k_slice[1]]
+            W32, group, world_size, rank = W_local, None, 1, 0
         self.group, self.world, self.rank = group, int(world_size), int(rank)
         self.n_local = int(n_paths_local)
         self.n_total = self.n_local * self.world
@@ -211,3 +225,19 @@ class PathEngine:
     def terminal(self) -> np.ndarray:
         self.synchronize()
         return self.d_terminal.cpu().numpy()
+
+    def gathered_stats(self) -> np.ndarray:
+        """shard='portfolios': all ranks' records in portfolio order ([K_all] mcp_stats), one all_gather."""
+        if self.shard != "portfolios":
+            return self.stats()
+        torch = self.torch
+        self.synchronize()
+        words = self.k_chunk * _ffi.STATS_DTYPE.itemsize // 8
+        mine = self.ws[_ffi.WS_STATS][:words].contiguous()
+        if self.gather_world > 1:
+            out = torch.empty(self.gather_world * words, dtype=torch.int64, device=self.device)
+            torch.distributed.all_gather_into_tensor(out, mine, group=self.gather_group)
+        else:
+            out = mine
+        rec = out.cpu().numpy().view(np.uint8).view(_ffi.STATS_DTYPE)
+        return rec[:self.k_all].copy() if self.gather_world * self.k_chunk >= self.k_all else rec.copy()

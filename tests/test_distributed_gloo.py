@@ -91,3 +91,58 @@ def test_two_ranks_equal_one_rank_and_reference(tmp_path, K):
         for key in ("mean", "std", "sharpe", "cvar"):         # fp64 sums: association differs across ranks
             assert float.fromhex(a[key]) == pytest.approx(float.fromhex(b[key]), rel=1e-13)
             assert float.fromhex(a[key]) == pytest.approx(want[key], rel=1e-12)
+
+
+PF_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from monte_carlo_portfolio_amd import synthetic
+from monte_carlo_portfolio_amd.engine import PathEngine
+from monte_carlo_portfolio_amd.simulate import prepare_inputs
+from fake_kernels import FakeKernels
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+mu, cov = synthetic.synthetic_market(8)
+W = synthetic.dirichlet_weights(8, 5)                      # 5 portfolios over 2 ranks: 3 + 2 (ragged)
+mu32, L, W32 = prepare_inputs(mu, cov, W)
+kc = 3
+Wl = np.zeros((kc, 8), np.float32); sl = W32[rank * kc:(rank + 1) * kc]; Wl[:len(sl)] = sl
+eng = PathEngine(mu32, L, W32, 12, 2000, device="cpu", kernels=FakeKernels(mu32, L, Wl), rf=0.002,
+                 group=dist.group.WORLD, world_size=world, rank=rank, shard="portfolios")
+eng.step(seed=77, path_base=0)
+st = eng.gathered_stats()
+out = [{{k: (int(st[i][k]) if k in ("n", "n_tail") else float(st[i][k]).hex()) for k in st.dtype.names}} for i in range(len(st))]
+open({out!r} + str(rank), "w").write(json.dumps(out))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_portfolio_sharding_two_ranks(tmp_path):
+    """configs[4] sharding: each rank walks all paths for its slice of W; the gathered records must equal the
+    reference definitions applied per portfolio (common random numbers across ranks)."""
+    from monte_carlo_portfolio_amd import synthetic
+    from monte_carlo_portfolio_amd.simulate import prepare_inputs
+    from oracle import mc_oracle, ref_stats
+    out = str(tmp_path / "pf_")
+    script = tmp_path / "pf_worker.py"
+    script.write_text(PF_WORKER.format(root=ROOT, out=out))
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, o.decode()[-3000:]
+    res = [json.load(open(out + str(r))) for r in range(2)]
+    assert res[0] == res[1] and len(res[0]) == 5
+    mu, cov = synthetic.synthetic_market(8)
+    W = synthetic.dirichlet_weights(8, 5)
+    mu32, L, W32 = prepare_inputs(mu, cov, W)
+    term = mc_oracle.simulate(mu32, L, W32, 12, 2000, 77)
+    for k in range(5):
+        want = ref_stats.path_stats(term[k], rf=0.002)
+        assert res[0][k]["n"] == 2000 and res[0][k]["n_tail"] == want["n_tail"]
+        assert float.fromhex(res[0][k]["var"]) == want["var"]
+        assert float.fromhex(res[0][k]["sharpe"]) == pytest.approx(want["sharpe"], rel=1e-12)
