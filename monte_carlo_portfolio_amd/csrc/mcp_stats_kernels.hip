@@ -278,13 +278,21 @@ __global__ void select_init_kernel(int K, uint64_t rank_lo, uint64_t rank_hi, Se
   state[i] = SelectState{0u, 0u, (i & 1) ? rank_hi : rank_lo};
 }
 
+// blocks per portfolio of a streaming pass over n values: >= 8 Ki values per 256-thread block, at most `cap`
+static int stream_grid(uint64_t n, int cap) {
+  uint64_t g = (n + 8191) / 8192;
+  if (g < 1) g = 1;
+  return (int)(g > (uint64_t)cap ? (uint64_t)cap : g);
+}
+
 // ---- launch wrappers (enqueue only) -------------------------------------------------------------
 hipError_t launch_moments(const mcp_params& prm, int K, const float* terminal, uint64_t stride, uint64_t n,
                           mcp_moments* partials, mcp_moments* out, hipStream_t s) {
-  moments_partial_kernel<<<dim3(MOMENTS_GRID, (unsigned)K), 256, 0, s>>>(prm, terminal, stride, n, partials);
+  const int gx = stream_grid(n, MOMENTS_GRID);
+  moments_partial_kernel<<<dim3((unsigned)gx, (unsigned)K), 256, 0, s>>>(prm, terminal, stride, n, partials);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  moments_kernel<<<K, 256, 0, s>>>(partials, MOMENTS_GRID, out);
+  moments_kernel<<<K, 256, 0, s>>>(partials, gx, out);
   return hipGetLastError();
 }
 
@@ -297,7 +305,8 @@ hipError_t launch_select_hist(int K, const float* terminal, uint64_t stride, uin
                               const SelectState* state, unsigned long long* hist, hipStream_t s) {
   hipError_t e = hipMemsetAsync(hist, 0, (size_t)K * 2 * MCP_SELECT_BINS * sizeof(unsigned long long), s);
   if (e != hipSuccess) return e;
-  uint64_t bx = (n + (uint64_t)SELECT_BLOCK * 8 - 1) / ((uint64_t)SELECT_BLOCK * 8);
+  // >= 16 Ki elements per block: zeroing and flushing the 2 x 2048-bin LDS histograms costs as much as ~4 Ki elements
+  uint64_t bx = (n + 16383) / 16384;
   if (bx < 1) bx = 1;
   if (bx > 1024) bx = 1024;
   select_hist_kernel<<<dim3((unsigned)bx, (unsigned)K), SELECT_BLOCK, 0, s>>>(terminal, stride, n, pass, state, hist);
@@ -316,10 +325,11 @@ hipError_t launch_quantile(const mcp_params& prm, int K, double gamma, const Sel
 
 hipError_t launch_tail(const mcp_params& prm, int K, const float* terminal, uint64_t stride, uint64_t n,
                        const Quantile* quant, double* partial, double* tail, hipStream_t s) {
-  tail_kernel<<<dim3(TAIL_GRID, (unsigned)K), 256, 0, s>>>(prm, terminal, stride, n, quant, partial);
+  const int gx = stream_grid(n, TAIL_GRID);
+  tail_kernel<<<dim3((unsigned)gx, (unsigned)K), 256, 0, s>>>(prm, terminal, stride, n, quant, partial);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  tail_sum_kernel<<<K, 64, 0, s>>>(partial, TAIL_GRID, tail);
+  tail_sum_kernel<<<K, 64, 0, s>>>(partial, gx, tail);
   return hipGetLastError();
 }
 
