@@ -22,6 +22,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL; must be set before HIP initialises
 
 import numpy as np  # noqa: E402
 
@@ -81,7 +82,6 @@ def main():
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         group = dist.group.WORLD
 
