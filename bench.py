@@ -81,7 +81,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local_rank)
     group = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:     # under torch.distributed.run also with one rank (exercises RCCL)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         group = dist.group.WORLD
 
@@ -125,7 +125,7 @@ def main():
                      native_math=args.native_math)
 
     def sync():
-        if world > 1:
+        if group is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -137,7 +137,7 @@ def main():
         eng.step(seed, path_base=0)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if group is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -231,7 +231,7 @@ def main():
             out["sharpe_rel_err"] = abs(g["sharpe"] - want["sharpe"]) / abs(want["sharpe"])
             out["var_check_paths"] = n
         print(json.dumps(out))
-    if world > 1:
+    if group is not None:
         dist.destroy_process_group()
 
 

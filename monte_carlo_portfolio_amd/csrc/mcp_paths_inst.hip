@@ -1,5 +1,7 @@
 // mcp_paths_inst.hip -- instantiates mc_paths_kernel for ONE value of NB (= ceil(N/4), -DMCP_NB=n).
 // Built once per NB in 1..16 so the 16 translation units compile in parallel (see Makefile).
+#include <cstdlib>
+
 #include "mcp_paths.h"
 #include "mcp_stats_kernels.h"
 
@@ -12,9 +14,17 @@
 
 namespace mcp {
 
+// MCP_PATHS_LDS_PAD (bytes, env, experiment): extra dynamic LDS per workgroup.  4608 on top of the 16 KiB of tables
+// makes 7 instead of 8 workgroups fit a CU, which leaves one wave slot per SIMD free for the small statistics
+// kernels of the previous batch when batches are pipelined (engine.PathEngine).
+static size_t lds_pad() {
+  static const size_t pad = [] { const char* e = getenv("MCP_PATHS_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+  return pad;
+}
+
 template <int KT, int PPT, bool NATIVE>
 static hipError_t go(const PathArgs& args, int grid, hipStream_t stream) {
-  mc_paths_kernel<MCP_NB, KT, PPT, NATIVE><<<grid, PATH_BLOCK, 0, stream>>>(args);
+  mc_paths_kernel<MCP_NB, KT, PPT, NATIVE><<<grid, PATH_BLOCK, lds_pad(), stream>>>(args);
   return hipGetLastError();
 }
 

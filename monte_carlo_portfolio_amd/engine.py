@@ -128,7 +128,7 @@ class PathEngine:
             b["moments"] = b["ws"][_ffi.WS_MOMENTS].view(torch.float64).view(K, 5)
             b["hist"] = b["ws"][_ffi.WS_HIST]                                  # int64 counts [K][2][2048]
             b["tail"] = b["ws"][_ffi.WS_TAIL].view(torch.float64).view(K, 2)
-            if self.world > 1:
+            if self.group is not None:
                 b["gather"] = torch.empty((self.world * K, 5), dtype=torch.float64, device=self.device)
             self.bufs.append(b)
         self.cur = 0                                   # buffer the NEXT step writes
@@ -162,7 +162,7 @@ class PathEngine:
 
     def _enqueue_stats(self, b):
         k, K, n, ws = self.k, self.K, self.n_local, b["ws"]
-        dist = self.torch.distributed if self.world > 1 else None
+        dist = self.torch.distributed if self.group is not None else None      # also exercised with 1 rank
         k.moments(self.prm, b["terminal"], n, ws[_ffi.WS_PARTIALS], ws[_ffi.WS_MOMENTS])
         if dist is not None:
             dist.all_gather_into_tensor(b["gather"], b["moments"], group=self.group)

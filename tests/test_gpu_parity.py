@@ -381,3 +381,31 @@ def test_config2_shard_scale_properties(gpu_ctx):
     mu32, L, W32 = prepare_inputs(mu, cov, w)
     ref = mc_oracle.simulate(mu32, L, W32, T, 4096, SEED, path_begin=3 * P + P - 4096)      # the shard's last paths
     assert np.array_equal(r["terminal"][-4096:].view(np.uint32), ref[0].view(np.uint32))
+
+
+def test_enqueue_only_steps_capture_into_a_hip_graph(gpu_ctx):
+    """The device-level entry points only enqueue (no allocation, no sync, no host copy): a whole pass captured into
+    a hipGraph through torch's capture stream replays to the same bits."""
+    import torch
+    from monte_carlo_portfolio_amd.engine import PathEngine
+    N, T, P = 16, 30, 40_000
+    mu, cov = synthetic.synthetic_market(N)
+    mu32, L, W32 = prepare_inputs(mu, cov, synthetic.dirichlet_weights(N, 3))
+    eng = PathEngine(mu32, L, W32, T, P, pipeline=False)
+    eng.step(SEED)                                  # warm-up: builds the per-device Box-Muller tables outside capture
+    want = eng.stats()
+    term = eng.terminal().copy()
+    eng.d_terminal.zero_()
+    eng.ws[_ffi.WS_STATS].zero_()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        eng.step(SEED)
+    for _ in range(3):
+        eng.d_terminal.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(eng.terminal(), term)
+        got = eng.stats()
+        for key in want.dtype.names:
+            assert np.array_equal(got[key], want[key]), key
