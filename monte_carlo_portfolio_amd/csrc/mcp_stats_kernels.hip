@@ -285,6 +285,10 @@ static int stream_grid(uint64_t n, int cap) {
   return (int)(g > (uint64_t)cap ? (uint64_t)cap : g);
 }
 
+__global__ void __launch_bounds__(256) zero_u64_kernel(unsigned long long* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0ull;
+}
+
 // ---- launch wrappers (enqueue only) -------------------------------------------------------------
 hipError_t launch_moments(const mcp_params& prm, int K, const float* terminal, uint64_t stride, uint64_t n,
                           mcp_moments* partials, mcp_moments* out, hipStream_t s) {
@@ -303,7 +307,11 @@ hipError_t launch_select_init(int K, uint64_t rank_lo, uint64_t rank_hi, SelectS
 
 hipError_t launch_select_hist(int K, const float* terminal, uint64_t stride, uint64_t n, int pass,
                               const SelectState* state, unsigned long long* hist, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(hist, 0, (size_t)K * 2 * MCP_SELECT_BINS * sizeof(unsigned long long), s);
+  // own zero-fill kernel rather than hipMemsetAsync: a captured memset node replayed wrongly from the second
+  // hipGraphLaunch on (ROCm 7.0 runtime bundled with torch); a plain kernel node replays exactly
+  const size_t words = (size_t)K * 2 * MCP_SELECT_BINS;
+  zero_u64_kernel<<<(unsigned)((words + 1023) / 1024 > 4096 ? 4096 : (words + 1023) / 1024), 256, 0, s>>>(hist, words);
+  hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // >= 16 Ki elements per block: zeroing and flushing the 2 x 2048-bin LDS histograms costs as much as ~4 Ki elements
   uint64_t bx = (n + 16383) / 16384;
