@@ -230,6 +230,26 @@ def main():
             out["var_abs_err"] = abs(g["var"] - want["var"])
             out["sharpe_rel_err"] = abs(g["sharpe"] - want["sharpe"]) / abs(want["sharpe"])
             out["var_check_paths"] = n
+            # side figure: the reference's own loop, app.py:699-717, on historical rows
+            from monte_carlo_portfolio_amd import sweep
+            Rm = np.random.default_rng(0).normal(0.0005, 0.02, (252, N_ASSETS))
+            Wm = synthetic.dirichlet_weights(N_ASSETS, 10_000)
+            Rc, mean_h, cov_h = sweep.sweep_inputs(Rm, 252)
+            sweep.score_portfolios(Rc, mean_h, cov_h, Wm[:16], 0.03)
+            t0 = time.perf_counter()
+            sg = sweep.score_portfolios(Rc, mean_h, cov_h, Wm, 0.03)
+            t_gpu = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            series = Rc @ Wm.T
+            v_np = np.percentile(series, (1 - 0.95) * 100, axis=0)
+            np.where(series <= v_np, series, 0.0).sum(axis=0) / (series <= v_np).sum(axis=0)
+            (Wm @ mean_h - 0.03) / np.sqrt(np.einsum("pi,ij,pj->p", Wm, cov_h, Wm))
+            t_np = time.perf_counter() - t0
+            out["historical_sweep"] = {
+                "workload": "10,000 Dirichlet portfolios x 252 rows x 16 assets, loop body app.py:708-713",
+                "gpu_portfolios_per_s_incl_pcie": 10_000 / t_gpu, "numpy_vectorised_portfolios_per_s": 10_000 / t_np,
+                "reference_loop_portfolios_per_s": 1940, "reference_loop_note": "app.py:699-717 as written, 1 core, survey container (BASELINE.md section 2)",
+                "var_max_abs_diff_vs_numpy": float(np.max(np.abs(sg["var_95"] - v_np)))}
         print(json.dumps(out))
     if group is not None:
         dist.destroy_process_group()

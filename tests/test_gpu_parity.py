@@ -409,3 +409,28 @@ def test_enqueue_only_steps_capture_into_a_hip_graph(gpu_ctx):
         got = eng.stats()
         for key in want.dtype.names:
             assert np.array_equal(got[key], want[key]), key
+
+
+def test_context_is_thread_safe(gpu_ctx):
+    """Streamlit runs one script thread per session: concurrent calls on the shared context must
+    serialise inside the library and each return its own, correct result."""
+    import threading
+    mu, cov = synthetic.synthetic_market(8)
+    w = synthetic.equal_weights(8)
+    seeds = list(range(100, 108))
+    want = {s: simulate_paths(mu, cov, w, n_steps=20, n_paths=20_000 + s, seed=s) for s in seeds}
+    got, errs = {}, []
+
+    def work(s):
+        try:
+            for _ in range(3):
+                got[s] = simulate_paths(mu, cov, w, n_steps=20, n_paths=20_000 + s, seed=s)
+        except Exception as e:      # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(s,)) for s in seeds]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+    for s in seeds:
+        assert got[s] == want[s]
