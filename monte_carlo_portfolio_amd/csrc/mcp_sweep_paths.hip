@@ -21,7 +21,7 @@ namespace mcp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int NB, int MT, bool NATIVE>
+template <int NB, int MT, bool NATIVE, bool LOGC>
 __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs a) {
   constexpr int N4 = 4 * NB, KS = N4 / 2;   // KS k-steps of 2 assets
   typedef const __attribute__((address_space(4))) float* cfloat_p;
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
   const uint64_t g = a.path_begin + p;
   const uint32_t plo = (uint32_t)g, phi = (uint32_t)(g >> 32);
   const int k_base = blockIdx.y * 32 * MT;
-  const bool logc = a.compounding == MCP_COMPOUND_LOG;
+  constexpr bool logc = LOGC;      // compile-time: a run-time flag turns the compounding into fma + add + select
 
   float areg[MT][KS];
 #pragma unroll
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
 // the second barrier every wave reads its MFMA B operands straight from the r image (lane l: r[2kk + (l>>5)]
 // [32nt + (l&31)], conflict-free), so no permlane is needed.  Two barriers per step, z/r double-buffered by the
 // parity of t.  Same arithmetic, same order: bit-identical to mc_sweep_kernel and to the oracle.
-template <int NB, bool NATIVE>
+template <int NB, bool NATIVE, bool LOGC>
 __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const PathArgs a) {
   constexpr int N4 = 4 * NB, KS = N4 / 2, MT = 4;
   typedef const __attribute__((address_space(4))) float* cfloat_p;
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
   const uint64_t g = a.path_begin + p;
   const uint32_t plo = (uint32_t)g, phi = (uint32_t)(g >> 32);
   const int k_base = (blockIdx.y * 4 + wave) * 32 * MT;
-  const bool logc = a.compounding == MCP_COMPOUND_LOG;
+  constexpr bool logc = LOGC;      // compile-time: a run-time flag turns the compounding into fma + add + select
 
   float areg[MT][KS];
 #pragma unroll
@@ -236,8 +236,9 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
 template <int NB>
 static hipError_t go_shared(bool native, const PathArgs& args, hipStream_t stream) {
   const dim3 grid((unsigned)((args.n_paths + 63) / 64), (unsigned)((args.n_portfolios + 511) / 512));
-  if (native) mc_sweep_shared_kernel<NB, true><<<grid, PATH_BLOCK, 0, stream>>>(args);
-  else mc_sweep_shared_kernel<NB, false><<<grid, PATH_BLOCK, 0, stream>>>(args);
+  const bool lg = args.compounding == MCP_COMPOUND_LOG;
+  if (native) { if (lg) mc_sweep_shared_kernel<NB, true, true><<<grid, PATH_BLOCK, 0, stream>>>(args); else mc_sweep_shared_kernel<NB, true, false><<<grid, PATH_BLOCK, 0, stream>>>(args); }
+  else { if (lg) mc_sweep_shared_kernel<NB, false, true><<<grid, PATH_BLOCK, 0, stream>>>(args); else mc_sweep_shared_kernel<NB, false, false><<<grid, PATH_BLOCK, 0, stream>>>(args); }
   return hipGetLastError();
 }
 
@@ -255,7 +256,11 @@ hipError_t launch_sweep_shared(int nb, bool native, const PathArgs& args, hipStr
 // grid.x = ceil(n_paths / 256), grid.y = ceil(K / (32 MT))
 template <int NB>
 static hipError_t go_nb(int mt, bool native, const PathArgs& args, const dim3 grid, hipStream_t stream) {
-#define MCP_GO(M, NAT) mc_sweep_kernel<NB, M, NAT><<<grid, PATH_BLOCK, 0, stream>>>(args)
+#define MCP_GO(M, NAT)                                                                               \
+  do {                                                                                               \
+    if (args.compounding == MCP_COMPOUND_LOG) mc_sweep_kernel<NB, M, NAT, true><<<grid, PATH_BLOCK, 0, stream>>>(args); \
+    else mc_sweep_kernel<NB, M, NAT, false><<<grid, PATH_BLOCK, 0, stream>>>(args);                  \
+  } while (0)
   if (mt == 1) { if (native) MCP_GO(1, true); else MCP_GO(1, false); }
   else if (mt == 2) { if (native) MCP_GO(2, true); else MCP_GO(2, false); }
   else if (mt == 4) { if (native) MCP_GO(4, true); else MCP_GO(4, false); }
