@@ -434,3 +434,22 @@ def test_context_is_thread_safe(gpu_ctx):
     assert not errs
     for s in seeds:
         assert got[s] == want[s]
+
+
+def test_extreme_inputs_negative_values_and_alpha_range(gpu_ctx):
+    """Huge per-step volatility drives 1 + rho below zero: terminal values of both signs, zeros and wide dynamic
+    range go through the order-preserving key of the radix select; alpha near both ends; one-step walks."""
+    rng = np.random.default_rng(5)
+    N = 4
+    A = rng.normal(size=(N, N))
+    cov = A @ A.T * 0.3 + np.eye(N) * 0.05                      # ~60-100 % vol PER STEP
+    mu = np.full(N, 0.01)
+    w = np.array([0.7, 0.1, 0.1, 0.1])
+    mu32, L, W32 = prepare_inputs(mu, cov, w)
+    for T, P, alpha in ((9, 30_000, 0.95), (1, 5000, 0.999), (3, 20_001, 0.5), (25, 10_000, 0.9)):
+        got = simulate_paths(mu, cov, w, n_steps=T, n_paths=P, seed=SEED + T, store=True, alpha=alpha, rf=0.01)
+        ref = mc_oracle.simulate(mu32, L, W32, T, P, SEED + T)
+        assert np.array_equal(got["terminal"].view(np.uint32), ref[0].view(np.uint32))
+        if T > 1:
+            assert (ref[0] < 0).any() and (ref[0] > 0).any()
+        assert_stats(got, ref[0], 1.0, "simple", alpha, 0.01)
