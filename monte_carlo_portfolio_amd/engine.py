@@ -82,7 +82,7 @@ class PathEngine:
 
     def __init__(self, mu32, chol32, W32, n_steps, n_paths_local, *, compounding="simple", v0=1.0, alpha=0.95,
                  rf=0.0, native_math=False, device=None, group=None, world_size=1, rank=0, kernels=None,
-                 pipeline=True, shard="paths"):
+                 pipeline=True, shard="paths", n_buffers=None):
         import torch
 
         self.torch = torch
@@ -113,7 +113,9 @@ class PathEngine:
         self.prm = _ffi.make_params(mu32.shape[0], n_steps, K, compounding, v0, alpha, rf, native_math)
         self.rank_lo, self.rank_hi, self.gamma = _ffi.percentile_rank(self.n_total, alpha)
         self.pipeline = bool(pipeline) and self.device.type == "cuda"
-        self.n_buf = 2 if self.pipeline else 1
+        # in-flight batches: 2 hide the statistics tail on one GPU; with collectives in that tail (each one waits for
+        # a free wave slot beside the running path kernel on EVERY rank) 4 keep the path streams from stalling
+        self.n_buf = (int(n_buffers) if n_buffers else (4 if self.group is not None else 2)) if self.pipeline else 1
 
         lib = _ffi.lib()
         packed = _ffi.pack_params(mu32, chol32, W32)
@@ -137,9 +139,9 @@ class PathEngine:
             # one path stream per buffer: the next batch's path kernel fills the CUs that the previous one's
             # last (partial) round of waves leaves idle
             self.s_paths = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
-            self.s_stats = torch.cuda.Stream(self.device)
-            self.ev_paths = [torch.cuda.Event() for _ in range(2)]
-            self.ev_stats = [torch.cuda.Event() for _ in range(2)]
+            self.s_stats = torch.cuda.Stream(self.device, priority=-1)   # small kernels: dispatch ahead of path blocks
+            self.ev_paths = [torch.cuda.Event() for _ in range(self.n_buf)]
+            self.ev_stats = [torch.cuda.Event() for _ in range(self.n_buf)]
             for e in self.ev_stats:
                 e.record(torch.cuda.current_stream(self.device))
             # buffers were filled on the current stream: order both pipeline streams after it
@@ -191,7 +193,7 @@ class PathEngine:
             self._enqueue_stats(b)
         else:
             torch = self.torch
-            sp = self.s_paths[i]
+            sp = self.s_paths[i % 2]
             with torch.cuda.stream(sp):
                 sp.wait_event(self.ev_stats[i])                 # the pass that last used this buffer is done
                 self._enqueue_paths(b, seed, path_base)

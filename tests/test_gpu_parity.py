@@ -333,19 +333,23 @@ def test_pipelined_engine_batches_are_independent_and_correct(gpu_ctx):
     mu32, L, W32 = prepare_inputs(mu, cov, w)
     eng = PathEngine(mu32, L, W32, T, P)
     assert eng.pipeline and eng.n_buf == 2
+    eng4 = PathEngine(mu32, L, W32, T, P, n_buffers=4)
     seeds = [11, 12, 13, 14, 15]
     for s in seeds:                       # back to back, no host sync in between
         eng.step(s)
     eng.synchronize()
     want = {s: simulate_paths(mu, cov, w, n_steps=T, n_paths=P, seed=s) for s in seeds[-2:]}
     for back, s in ((0, seeds[-1]), (1, seeds[-2])):       # the two batches still resident in the double buffer
-        b = eng.bufs[(eng.last - back) % 2]
+        b = eng.bufs[(eng.last - back) % eng.n_buf]
         raw = b["ws"][_ffi.WS_STATS].cpu().numpy().view(np.uint8)[:_ffi.STATS_DTYPE.itemsize].view(_ffi.STATS_DTYPE)[0]
         for key in raw.dtype.names:
             assert raw[key] == want[s][key], (s, key)
     plain = PathEngine(mu32, L, W32, T, P, pipeline=False)
     plain.step(seeds[-1])
     assert plain.stats()[0] == eng.stats()[0]
+    for s in seeds + [16, 17, 18, seeds[-1]]:             # 9 batches through 4 buffers
+        eng4.step(s)
+    assert eng4.n_buf == 4 and eng4.stats()[0] == plain.stats()[0]
 
 
 def test_config3_shape_64_assets_1260_steps(gpu_ctx):
