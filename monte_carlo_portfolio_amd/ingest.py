@@ -73,8 +73,10 @@ def read_csv_file(file, compat: bool = False, report=None):
 
 
 def asset_name(filename: str) -> str:
-    """app.py:389: name = file.name.split('.')[0]."""
-    return filename.split(".")[0]
+    """app.py:389: name = file.name.split('.')[0] (Streamlit upload names carry no directory; a path's directory
+    part is dropped here so files opened from disk get the same names)."""
+    import os
+    return os.path.basename(filename).split(".")[0]
 
 
 def dedupe_names(names):

@@ -110,3 +110,16 @@ def test_large_sweep_shape(gpu_ctx):
     want_cvar = np.array([series[:, p][series[:, p] <= s["var_95"][p]].mean() for p in range(0, 10_000, 97)])
     np.testing.assert_allclose(s["cvar_95"][::97], want_cvar, rtol=1e-11)
     assert int(np.argmax(s["sharpe"])) == int(np.argmax((W @ mean - 0.03) / np.sqrt(np.einsum("pi,ij,pj->p", W, cov, W))))
+
+
+def test_example_pipeline_runs_end_to_end(gpu_ctx, capsys):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pipeline_example", os.path.join(os.path.dirname(HERE), "examples", "pipeline.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    data = os.path.join(HERE, "golden", "data")
+    res, sim = mod.main([os.path.join(data, f) for f in G["files"]], n_paths=50_000)
+    out = capsys.readouterr().out
+    assert "opt_idx" in out and sim["n"] == 50_000 and sim["var"] < sim["mean"] and sim["cvar"] <= sim["var"]
+    assert res["Monte Carlo"]["all_weights"].shape == (2500, 3) and "Avalanche Historical Data" in out
+    assert set(res) == set(sweep.METHODS)
