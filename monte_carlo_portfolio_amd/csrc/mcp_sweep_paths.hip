@@ -95,9 +95,8 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
 #pragma unroll
         for (int kk = 0; kk < KS; kk++)
           rho = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[mt][kk], nt ? b1[kk] : b0[kk], rho, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 16; q++)
-          V[mt][nt][q] = logc ? (V[mt][nt][q] + rho[q]) : fma32(V[mt][nt][q], rho[q], V[mt][nt][q]);
+        if constexpr (logc) V[mt][nt] = V[mt][nt] + rho;
+        else V[mt][nt] = __builtin_elementwise_fma(V[mt][nt], rho, V[mt][nt]);      // 8 v_pk_fma_f32
       }
     }
   }
@@ -212,9 +211,8 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
         f32x16 rho = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int kk = 0; kk < KS; kk++) rho = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[mt][kk], b[nt][kk], rho, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 16; q++)
-          V[mt][nt][q] = logc ? (V[mt][nt][q] + rho[q]) : fma32(V[mt][nt][q], rho[q], V[mt][nt][q]);
+        if constexpr (logc) V[mt][nt] = V[mt][nt] + rho;
+        else V[mt][nt] = __builtin_elementwise_fma(V[mt][nt], rho, V[mt][nt]);      // 8 v_pk_fma_f32
       }
     }
   }
