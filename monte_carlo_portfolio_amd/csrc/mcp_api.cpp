@@ -59,16 +59,17 @@ int check_params(const mcp_params* p) {
 }
 
 int paths_per_thread(const mcp_params* p) {
+#ifdef MCP_EXP_PPT2
   static const int env_ppt = [] {
     const char* e = getenv("MCP_PPT");
-#ifdef MCP_DEFAULT_PPT
-    return e ? atoi(e) : MCP_DEFAULT_PPT;
-#else
     return e ? atoi(e) : 1;
-#endif
   }();
   const int nb = (p->n_assets + 3) / 4;
   return (env_ppt == 2 && nb <= 4 && p->n_portfolios == 1) ? 2 : 1;
+#else
+  (void)p;
+  return 1;
+#endif
 }
 
 const mcp::launch_paths_fn k_launch[16] = {
