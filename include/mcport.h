@@ -41,8 +41,9 @@ enum {
 };
 
 enum {
-    MCP_FLAG_NATIVE_MATH = 1   /* Box-Muller on v_log/v_sqrt/v_sin/v_cos hardware approximations:
-                                  faster, NOT bit-reproducible against the oracle (tolerance parity) */
+    MCP_FLAG_NATIVE_MATH = 1   /* normals by Box-Muller on the v_log/v_sqrt/v_sin/v_cos hardware approximations instead
+                                  of the spec's inverse-CDF table: statistically equivalent draws from the same Philox
+                                  stream, NOT comparable to the oracle value by value */
 };
 
 typedef struct mcp_ctx mcp_ctx;
@@ -166,13 +167,12 @@ int mcp_launch_tail(const mcp_params *prm, const float *d_terminal, uint64_t ter
 int mcp_launch_stats(const mcp_params *prm, const void *d_moments, const void *d_quant, const void *d_tail,
                      void *d_stats, void *stream);
 
-/* The normal generator on its own: Box-Muller (SPEC.md section 3) of n caller-supplied 32-bit pairs on the
- * device, (xa, xb) -> (s sin, s cos).  flags: MCP_FLAG_NATIVE_MATH or 0. */
-int mcp_launch_box_muller(const uint32_t *d_xa, const uint32_t *d_xb, uint64_t n, float *d_z_sin, float *d_z_cos,
-                          int flags, void *stream);
+/* The normal generator on its own: d_z[i] = inverse-CDF normal (SPEC.md section 3) of the 32-bit word d_x[i]. */
+int mcp_launch_normals(const uint32_t *d_x, uint64_t n, float *d_z, void *stream);
 
-/* Test hook: d_out[i] = the kernel's correctly rounded sqrt of d_in[i] (d_in in {0} U [2^-24, 64)). */
-int mcp_launch_sqrt(const float *d_in, float *d_out, uint64_t n, void *stream);
+/* The inverse-CDF coefficient table the kernels use (1056 x 4 floats; pure CPU): lets a test compare it with the
+ * oracle's copy. */
+int mcp_icdf_table(float *out, size_t out_len);
 
 /* Host helpers shared by both levels (pure CPU). */
 uint32_t mcp_float_to_key(float v);

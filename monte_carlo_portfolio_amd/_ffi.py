@@ -86,8 +86,8 @@ SIGNATURES = {
     "mcp_launch_quantile": (_int, [_PP, ctypes.c_double, _vp, _vp, _vp]),
     "mcp_launch_tail": (_int, [_PP, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "mcp_launch_stats": (_int, [_PP, _vp, _vp, _vp, _vp, _vp]),
-    "mcp_launch_box_muller": (_int, [_vp, _vp, _u64, _vp, _vp, _int, _vp]),
-    "mcp_launch_sqrt": (_int, [_vp, _vp, _u64, _vp]),
+    "mcp_launch_normals": (_int, [_vp, _u64, _vp, _vp]),
+    "mcp_icdf_table": (_int, [_f32p, ctypes.c_size_t]),
     "mcp_float_to_key": (ctypes.c_uint32, [ctypes.c_float]),
     "mcp_key_to_float": (ctypes.c_float, [ctypes.c_uint32]),
     "mcp_terminal_to_x": (ctypes.c_double, [_PP, ctypes.c_float]),

@@ -1,6 +1,6 @@
 // mcp_paths.h -- the fused Monte Carlo path kernel (template; instantiated per NB in mcp_paths_inst.hip).
 //
-//   mc_paths_kernel   N1+N2 of SURVEY.md section 8(a): Philox4x32-10 -> Box-Muller -> r = mu + L z ->
+//   mc_paths_kernel   N1+N2 of SURVEY.md section 8(a): Philox4x32-10 -> normals (inverse CDF) -> r = mu + L z ->
 //                     rho = w.r -> V <- V(1+rho) over T steps, entirely in registers; writes V_T
 //                     (4 B/path, coalesced).  All statistics are separate streaming passes over V_T.
 //                     Conventions inherited from the reference: fixed-weight portfolio return
@@ -31,7 +31,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct PathArgs {
   const float* __restrict__ packed;   // [mu N4][L row pairs N4(N4/2+1)][W Kpad*N4]  (mcp_pack_params)
   float* __restrict__ terminal;       // [K][stride]
-  const float2* __restrict__ tables;  // [2][BM_TAB]: sin/cos table then log table (built by tables_init_kernel)
+  const float4* __restrict__ tables;  // [ICDF_ENTRIES] inverse-CDF coefficient table (device copy of mcp_icdf_table.inc)
   uint64_t seed, path_begin, n_paths, stride;
   int32_t n_steps, n_portfolios, k_begin, compounding;
   float v0;
@@ -70,10 +70,10 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
   cfloat_p Lp = mu + N4;
   cfloat_p Wk = mu + N4 + N4 * (N4 / 2 + 1) + (size_t)a.k_begin * N4;
   const int kt = min(KT, a.n_portfolios - a.k_begin);   // live portfolios in this pass (uniform)
-  // Box-Muller tables: 16 KiB of LDS per block, filled once from the device-resident copy
-  __shared__ float2 s_sc[BM_TAB], s_lg[BM_TAB];
+  // inverse-CDF table: 16.5 KiB of LDS per block, filled once from the device-resident copy
+  __shared__ float4 s_tab[ICDF_ENTRIES];
   if constexpr (!NATIVE) {
-    for (int i = threadIdx.x; i < BM_TAB; i += PATH_BLOCK) { s_sc[i] = a.tables[i]; s_lg[i] = a.tables[BM_TAB + i]; }
+    for (int i = threadIdx.x; i < ICDF_ENTRIES; i += PATH_BLOCK) s_tab[i] = a.tables[i];
     __syncthreads();
   }
   PhiloxKeys ks = philox_keys((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
@@ -113,8 +113,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
         for (int e = 0; e < PPT; e++) {
           uint32_t x[4];
           philox4x32_10(blk, 0u, plo[e], phi[e], ks, x);
-          box_muller<NATIVE>(x[0], x[1], s_sc, s_lg, z[e][0 * NB + q], z[e][1 * NB + q]);
-          box_muller<NATIVE>(x[2], x[3], s_sc, s_lg, z[e][2 * NB + q], z[e][3 * NB + q]);
+          block_normals<NATIVE>(x, s_tab, z[e][0 * NB + q], z[e][1 * NB + q], z[e][2 * NB + q], z[e][3 * NB + q]);
         }
       }
       // r = mu + L z (row i: acc = mu_i, then j ascending), rho_k = sum_i w_ki r_i (i ascending)

@@ -36,10 +36,7 @@ MCP_DECL_NB(9) MCP_DECL_NB(10) MCP_DECL_NB(11) MCP_DECL_NB(12) MCP_DECL_NB(13) M
 // mcp_sweep_paths.hip: MFMA K-portfolio kernel (N <= 16); mt = 32-portfolio tiles per wave (1, 2 or 4)
 hipError_t launch_sweep_shared(int nb, bool native, const PathArgs& args, hipStream_t stream);
 hipError_t launch_sweep_paths(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream);
-hipError_t launch_box_muller(const uint32_t* xa, const uint32_t* xb, uint64_t n, const float2* tables, float* zs,
-                             float* zc, bool native, hipStream_t s);
-hipError_t launch_sqrt(const float* in, float* out, uint64_t n, hipStream_t s);
-hipError_t launch_tables_init(float2* tables, hipStream_t s);
+hipError_t launch_normals(const uint32_t* x, uint64_t n, const float4* table, float* z, hipStream_t s);
 hipError_t launch_moments(const mcp_params& prm, int K, const float* terminal, uint64_t stride, uint64_t n,
                           mcp_moments* partials, mcp_moments* out, hipStream_t s);
 hipError_t launch_select_init(int K, uint64_t rank_lo, uint64_t rank_hi, SelectState* state, hipStream_t s);

@@ -219,56 +219,21 @@ __global__ void stats_kernel(const mcp_params prm, int K, const mcp_moments* __r
   out[k] = s;
 }
 
-// Box-Muller tables (SPEC.md section 3.1): tables[0..1023] = (sin, cos)(2 pi (i + 1/2)/1024), tables[1024..2047] = log table.
-__global__ void __launch_bounds__(256) tables_init_kernel(float2* __restrict__ tables) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (uint32_t)BM_TAB) return;
-  float sn, cs;
-  sincos_poly((i << 22) + 0x00200000u, sn, cs);
-  tables[i] = make_float2(sn, cs);
-  tables[BM_TAB + i] = log_table_entry(i);
+// The normal generator on its own: z[i] = inverse-CDF normal of word x[i] (SPEC.md section 3); also what tests use
+// to hit edge inputs (both ends of every octave, u == 1/2, the deepest tail).
+__global__ void __launch_bounds__(256) normals_kernel(const uint32_t* __restrict__ x, uint64_t n,
+                                                      const float4* __restrict__ table, float* __restrict__ z) {
+  __shared__ float4 s_tab[ICDF_ENTRIES];
+  for (int i = threadIdx.x; i < ICDF_ENTRIES; i += 256) s_tab[i] = table[i];
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) z[i] = normal_icdf(x[i], s_tab);
 }
 
-hipError_t launch_tables_init(float2* tables, hipStream_t s) {
-  tables_init_kernel<<<BM_TAB / 256, 256, 0, s>>>(tables);
-  return hipGetLastError();
-}
-
-// Box-Muller transform of caller-supplied 32-bit pairs (SPEC.md section 3) -- the normal generator of the
-// path kernel exposed on its own; also what tests use to hit edge inputs (u == 1, xa == 0, quadrant seams).
-template <bool NATIVE>
-__global__ void __launch_bounds__(256) box_muller_kernel(const uint32_t* __restrict__ xa, const uint32_t* __restrict__ xb,
-                                                         uint64_t n, const float2* __restrict__ tables,
-                                                         float* __restrict__ zs, float* __restrict__ zc) {
-  __shared__ float2 s_sc[BM_TAB], s_lg[BM_TAB];
-  if constexpr (!NATIVE) {
-    for (int i = threadIdx.x; i < BM_TAB; i += 256) { s_sc[i] = tables[i]; s_lg[i] = tables[BM_TAB + i]; }
-    __syncthreads();
-  }
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-    float a, b;
-    box_muller<NATIVE>(xa[i], xb[i], s_sc, s_lg, a, b);
-    zs[i] = a;
-    zc[i] = b;
-  }
-}
-
-hipError_t launch_box_muller(const uint32_t* xa, const uint32_t* xb, uint64_t n, const float2* tables, float* zs,
-                             float* zc, bool native, hipStream_t s) {
+hipError_t launch_normals(const uint32_t* x, uint64_t n, const float4* table, float* z, hipStream_t s) {
   uint64_t g = (n + 255) / 256;
   if (g < 1) g = 1;
   if (g > 4096) g = 4096;
-  if (native) box_muller_kernel<true><<<(unsigned)g, 256, 0, s>>>(xa, xb, n, tables, zs, zc);
-  else box_muller_kernel<false><<<(unsigned)g, 256, 0, s>>>(xa, xb, n, tables, zs, zc);
-  return hipGetLastError();
-}
-
-// out[i] = sqrt_rn(in[i]) -- test hook for the exhaustive correct-rounding check of the device sqrt.
-__global__ void __launch_bounds__(256) sqrt_kernel(const float* __restrict__ in, float* __restrict__ out, uint64_t n) {
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) out[i] = sqrt_rn(in[i]);
-}
-hipError_t launch_sqrt(const float* in, float* out, uint64_t n, hipStream_t s) {
-  sqrt_kernel<<<4096, 256, 0, s>>>(in, out, n);
+  normals_kernel<<<(unsigned)g, 256, 0, s>>>(x, n, table, z);
   return hipGetLastError();
 }
 

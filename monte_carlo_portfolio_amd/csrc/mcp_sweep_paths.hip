@@ -29,9 +29,9 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
   cfloat_p Lp = mu + N4;
   const float* __restrict__ Wg = a.packed + N4 + N4 * (N4 / 2 + 1);   // [Kpad][N4], rows >= K are zero
 
-  __shared__ float2 s_sc[BM_TAB], s_lg[BM_TAB];
+  __shared__ float4 s_tab[ICDF_ENTRIES];
   if constexpr (!NATIVE) {
-    for (int i = threadIdx.x; i < BM_TAB; i += PATH_BLOCK) { s_sc[i] = a.tables[i]; s_lg[i] = a.tables[BM_TAB + i]; }
+    for (int i = threadIdx.x; i < ICDF_ENTRIES; i += PATH_BLOCK) s_tab[i] = a.tables[i];
     __syncthreads();
   }
   const PhiloxKeys ks = philox_keys((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
@@ -64,8 +64,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
     for (int q = 0; q < NB; q++) {
       uint32_t x[4];
       philox4x32_10((uint32_t)t * NB + q, 0u, plo, phi, ks, x);
-      box_muller<NATIVE>(x[0], x[1], s_sc, s_lg, z[0 * NB + q], z[1 * NB + q]);
-      box_muller<NATIVE>(x[2], x[3], s_sc, s_lg, z[2 * NB + q], z[3 * NB + q]);
+      block_normals<NATIVE>(x, s_tab, z[0 * NB + q], z[1 * NB + q], z[2 * NB + q], z[3 * NB + q]);
     }
     float r[N4];
 #pragma unroll
@@ -117,7 +116,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
 
 // ---- shared-draw variant: the four waves of a workgroup own the SAME 64 paths and 4 x 128 = 512 portfolios.
 // The per-step draw is split four ways and exchanged through LDS: wave w runs Philox blocks q = w, w+4, ...
-// and its Box-Muller pairs (z rows to LDS), then row pairs m = w, w+4, ... of the GEMV (r rows to LDS); after
+// and their normals (z rows to LDS), then row pairs m = w, w+4, ... of the GEMV (r rows to LDS); after
 // the second barrier every wave reads its MFMA B operands straight from the r image (lane l: r[2kk + (l>>5)]
 // [32nt + (l&31)], conflict-free), so no permlane is needed.  Two barriers per step, z/r double-buffered by the
 // parity of t.  Same arithmetic, same order: bit-identical to mc_sweep_kernel and to the oracle.
@@ -129,10 +128,10 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
   cfloat_p Lp = mu + N4;
   const float* __restrict__ Wg = a.packed + N4 + N4 * (N4 / 2 + 1);
 
-  __shared__ float2 s_sc[BM_TAB], s_lg[BM_TAB];
+  __shared__ float4 s_tab[ICDF_ENTRIES];
   __shared__ float s_z[2][N4][64], s_r[2][N4][64];
   if constexpr (!NATIVE) {
-    for (int i = threadIdx.x; i < BM_TAB; i += PATH_BLOCK) { s_sc[i] = a.tables[i]; s_lg[i] = a.tables[BM_TAB + i]; }
+    for (int i = threadIdx.x; i < ICDF_ENTRIES; i += PATH_BLOCK) s_tab[i] = a.tables[i];
   }
   __syncthreads();
   const PhiloxKeys ks = philox_keys((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
@@ -169,8 +168,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
         uint32_t x[4];
         philox4x32_10((uint32_t)t * NB + q, 0u, plo, phi, ks, x);
         float z0, z1, z2, z3;
-        box_muller<NATIVE>(x[0], x[1], s_sc, s_lg, z0, z1);
-        box_muller<NATIVE>(x[2], x[3], s_sc, s_lg, z2, z3);
+        block_normals<NATIVE>(x, s_tab, z0, z1, z2, z3);
         s_z[buf][0 * NB + q][lane] = z0;
         s_z[buf][1 * NB + q][lane] = z1;
         s_z[buf][2 * NB + q][lane] = z2;

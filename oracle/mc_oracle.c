@@ -18,9 +18,8 @@
  * oracle/ref_stats.py, which follows app.py:258-263 and app.py:711 and is pinned by goldens
  * generated from the reference itself (tests/golden/).
  *
- * Everything here is IEEE-754 binary32 with round-to-nearest-even, explicit fmaf(), and
- * correctly rounded sqrtf(); compile with -ffp-contract=off so the compiler adds no fusions of
- * its own.  The HIP kernel executes the same operations in the same order, so terminal values
+ * Everything here is IEEE-754 binary32 with round-to-nearest-even and explicit fmaf(); compile
+ * with -ffp-contract=off so the compiler adds no fusions of its own.  The HIP kernel executes the same operations in the same order, so terminal values
  * are compared BIT-EXACTLY.
  */
 #include <math.h>
@@ -64,101 +63,31 @@ MCO_INLINE void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 MCO_INLINE float u32_as_f32(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 MCO_INLINE uint32_t f32_as_u32(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
-/* ---- Box-Muller pair, SPEC.md section 3: table-driven, exact arithmetic ------------------------
- * Two 1024-entry tables (on the GPU they live in LDS):
- *   SC[i] = (sin, cos)(2 pi (i + 1/2) / 1024)    built with the fixed fp32 polynomial below (bin midpoints)
- *   LG[j] = (inv_c, -2 ln(1/inv_c))               c = midpoint of mantissa bin j of [sqrt(.5), sqrt(2)),
- *                                                 the bin holding 1.0 uses c = 1 exactly
- * Table construction uses only IEEE +,*,/,fma (binary32 and binary64), so it is reproducible
- * bit for bit on any IEEE machine; the HIP side builds the same tables in a device init kernel.  */
-#define NEG_2LN2 -0x1.62e43p+0f          /* -2 ln 2 rounded to binary32 */
-#define TWO_PI_2M32 0x1.921fb6p-30f      /* 2 pi / 2^32 rounded to binary32 */
-#define PI_1024 0x1.921fb6p-9f           /* 2^21 * TWO_PI_2M32 = pi/1024 (same significand) */
-/* sin(a) = a + a^3 S(a^2), cos(a) = 1 - a^2/2 + a^4 C(a^2), |a| <= pi/4 (tools/fit_coeffs.py) */
-#define SS0 -0x1.55554p-3f
-#define SS1  0x1.1105b4p-7f
-#define SS2 -0x1.98da62p-13f
-#define CC0  0x1.55554ap-5f
-#define CC1 -0x1.6c0c8cp-10f
-#define CC2  0x1.9a0256p-16f
+/* ---- normal transform, SPEC.md section 3: inverse CDF, table-driven, exact arithmetic -------------------------
+ * One 32-bit word -> one N(0,1) draw.  bit 31 = sign, low 31 bits v -> u = (v + 1/2) 2^-32 in [2^-33, 1/2];
+ * u's binary32 exponent E (94..126) and top 5 mantissa bits select one of 33 x 32 table entries holding a cubic
+ * in the remaining 18 mantissa bits; the cubic evaluates a(u) = -Phi^-1(u) >= 0 (Horner, fma).  On the GPU the
+ * table (16.5 KiB) lives in LDS.  The coefficients are DATA of the spec (icdf_table.inc, generated once by
+ * tools/fit_icdf_table.py from scipy.special.ndtri); the kernels carry their own identical copy.  */
+#define MCO_ICDF_ENTRIES 1056
+#define MCO_ICDF_E_LO 94
+static const float g_icdf[MCO_ICDF_ENTRIES][4] = {
+#include "icdf_table.inc"
+};
 
-#define MCO_TAB 1024
-static float g_sc[MCO_TAB][2];
-static float g_lg[MCO_TAB][2];
-static pthread_once_t g_tab_once = PTHREAD_ONCE_INIT;
-
-/* (sin, cos)(2 pi xb / 2^32): exact integer quadrant reduction + degree-7/8 polynomials */
-static void sincos_poly(uint32_t xb, float *sn_out, float *cs_out)
+MCO_INLINE float normal_icdf(uint32_t x)
 {
-    uint32_t y = xb + 0x20000000u;
-    int32_t r = (int32_t)(xb << 2) >> 2;                     /* xb - kq*2^30, in [-2^29, 2^29) */
-    float a = (float)r * TWO_PI_2M32;
-    float a2 = a * a;
-    float ps = fmaf(a2, SS2, SS1); ps = fmaf(a2, ps, SS0);
-    float sn = fmaf(a * a2, ps, a);
-    float pc = fmaf(a2, CC2, CC1); pc = fmaf(a2, pc, CC0);
-    float cs = fmaf(a2 * a2, pc, fmaf(a2, -0.5f, 1.0f));
-    uint32_t kq = y >> 30;                                   /* theta = kq*pi/2 + a */
-    float vs = (kq & 1u) ? cs : sn;
-    float vc = (kq & 1u) ? sn : cs;
-    if (kq & 2u) vs = -vs;                                   /* kq in {2,3} */
-    if (kq == 1u || kq == 2u) vc = -vc;
-    *sn_out = vs + 0.0f; *cs_out = vc + 0.0f;                /* -0 -> +0 */
+    float u = fmaf((float)(x & 0x7fffffffu), 0x1p-32f, 0x1p-33f);
+    uint32_t b = f32_as_u32(u) - ((uint32_t)MCO_ICDF_E_LO << 23);
+    const float *c = g_icdf[b >> 18];
+    float dc = u32_as_f32((b & 0x0003ffffu) | 0x3f800000u) - 0x1.04p+0f;      /* delta - 1/64, delta in [0, 1/32) */
+    float a = fmaf(c[3], dc, c[2]);
+    a = fmaf(a, dc, c[1]);
+    a = fmaf(a, dc, c[0]);
+    return u32_as_f32((f32_as_u32(a) & 0x7fffffffu) | (x & 0x80000000u));     /* |a| with the sign of bit 31 */
 }
 
-/* ln(x) for x in [0.7, 1.42], binary64, atanh series: only IEEE +,*,/ (no libm) */
-static double ln_series(double x)
-{
-    double y = (x - 1.0) / (x + 1.0), y2 = y * y, s = 0.0;
-    for (int n = 17; n >= 0; n--) s = s * y2 + 1.0 / (double)(2 * n + 1);
-    return 2.0 * y * s;
-}
-
-static void build_tables(void)
-{
-    for (uint32_t i = 0; i < MCO_TAB; i++) sincos_poly((i << 22) + 0x00200000u, &g_sc[i][0], &g_sc[i][1]);
-    for (uint32_t j = 0; j < MCO_TAB; j++) {
-        uint32_t lo = 0x3f3504f3u + (j << 13);
-        float c = u32_as_f32(lo + 0x1000u);
-        if (lo <= 0x3f800000u && 0x3f800000u < lo + 0x2000u) c = 1.0f;
-        float inv_c = 1.0f / c;
-        g_lg[j][0] = inv_c;
-        g_lg[j][1] = (c == 1.0f) ? 0.0f : (float)(-2.0 * ln_series(1.0 / (double)inv_c));
-    }
-}
-
-void mco_tables(float *sc /* [1024*2] */, float *lg /* [1024*2] */)
-{
-    pthread_once(&g_tab_once, build_tables);
-    memcpy(sc, g_sc, sizeof g_sc);
-    memcpy(lg, g_lg, sizeof g_lg);
-}
-
-/* sqrt: IEEE correctly rounded (sqrtss). */
-MCO_INLINE void box_muller(uint32_t xa, uint32_t xb, float *z_sin, float *z_cos)
-{
-    /* radius: u in [2^-32, 1], u = 2^k m, m in [sqrt(.5), sqrt(2)), -2 ln u = k(-2 ln 2) + LG[j] - 2 log1p(r) */
-    float u = fmaf((float)xa, 0x1p-32f, 0x1p-32f);
-    uint32_t ib = f32_as_u32(u) - 0x3f3504f3u;
-    int32_t k = (int32_t)ib >> 23;
-    uint32_t mant = ib & 0x007fffffu;
-    float m = u32_as_f32(mant + 0x3f3504f3u);
-    uint32_t j = mant >> 13;
-    float r = fmaf(m, g_lg[j][0], -1.0f);                    /* (m - c')/c', c' = 1/inv_c */
-    float w = r * (r - 2.0f);                                /* -2 log1p(r) to O(r^3) */
-    float t = fmaf((float)k, NEG_2LN2, g_lg[j][1]);
-    t = t + w;
-    float s = sqrtf(t);
-    /* angle: theta = 2 pi xb / 2^32 = theta_i + d, theta_i = midpoint of table bin i = xb >> 22, |d| <= pi/1024 */
-    uint32_t i = xb >> 22;
-    float d = fmaf((float)(xb & 0x003fffffu), TWO_PI_2M32, -PI_1024);   /* (xb mod 2^22 - 2^21) 2 pi / 2^32 */
-    float sc = g_sc[i][0], cc = g_sc[i][1];
-    float cd = fmaf(d * -0.5f, d, 1.0f);                     /* cos d */
-    float sn = fmaf(cc, d, sc * cd);                         /* sin(theta_i + d), sin d ~ d */
-    float cs = fmaf(-sc, d, cc * cd);
-    *z_sin = s * sn;
-    *z_cos = s * cs;
-}
+void mco_icdf_table(float *out /* [1056*4] */) { memcpy(out, g_icdf, sizeof g_icdf); }
 
 /* normals of one path-step: z[m*nb + q] = normal m of Philox block q   (SPEC.md section 2) */
 MCO_INLINE void step_normals(uint32_t k0, uint32_t k1, uint64_t path, uint32_t step, int nb, float *z)
@@ -167,8 +96,7 @@ MCO_INLINE void step_normals(uint32_t k0, uint32_t k1, uint64_t path, uint32_t s
         uint64_t blk = (uint64_t)step * (uint32_t)nb + (uint32_t)q;
         uint32_t x[4];
         philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)path, (uint32_t)(path >> 32), k0, k1, x);
-        box_muller(x[0], x[1], &z[0 * nb + q], &z[1 * nb + q]);
-        box_muller(x[2], x[3], &z[2 * nb + q], &z[3 * nb + q]);
+        for (int m = 0; m < 4; m++) z[m * nb + q] = normal_icdf(x[m]);
     }
 }
 
@@ -178,25 +106,17 @@ void mco_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }
 
-void mco_box_muller(uint32_t xa, uint32_t xb, float *z_sin, float *z_cos)
-{
-    pthread_once(&g_tab_once, build_tables);
-    box_muller(xa, xb, z_sin, z_cos);
-}
-
-/* n pairs at once (vector form for the accuracy tests) */
+/* n words at once (vector form for the accuracy tests) */
 MCO_CLONES
-void mco_box_muller_n(const uint32_t *xa, const uint32_t *xb, float *z_sin, float *z_cos, uint64_t n)
+void mco_normals_n(const uint32_t *x, float *z, uint64_t n)
 {
-    pthread_once(&g_tab_once, build_tables);
-    for (uint64_t i = 0; i < n; i++) box_muller(xa[i], xb[i], &z_sin[i], &z_cos[i]);
+    for (uint64_t i = 0; i < n; i++) z[i] = normal_icdf(x[i]);
 }
 
 MCO_CLONES
 void mco_step_normals(uint64_t seed, uint64_t path, uint32_t step, int n_assets, float *z /* [4*ceil(N/4)] */)
 {
     int nb = (n_assets + 3) / 4;
-    pthread_once(&g_tab_once, build_tables);
     step_normals((uint32_t)seed, (uint32_t)(seed >> 32), path, step, nb, z);
 }
 
@@ -260,7 +180,6 @@ int mco_simulate(int n_assets, int n_steps, int n_portfolios, int compounding, f
 {
     if (n_assets < 1 || n_assets > MCO_MAX_ASSETS || n_steps < 0 || n_portfolios < 1) return -1;
     if (n_threads < 1) n_threads = 1;
-    pthread_once(&g_tab_once, build_tables);
     if ((uint64_t)n_threads > n_paths) n_threads = n_paths ? (int)n_paths : 1;
     mco_job *jobs = (mco_job *)malloc(sizeof(mco_job) * n_threads);
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * n_threads);

@@ -31,12 +31,12 @@ def lib() -> ctypes.CDLL:
         L = ctypes.CDLL(build())
         L.mco_philox4x32_10.argtypes = [_u32p, _u32p, _u32p]
         L.mco_philox4x32_10.restype = None
-        L.mco_box_muller_n.argtypes = [_u32p, _u32p, _f32p, _f32p, ctypes.c_uint64]
-        L.mco_box_muller_n.restype = None
+        L.mco_normals_n.argtypes = [_u32p, _f32p, ctypes.c_uint64]
+        L.mco_normals_n.restype = None
+        L.mco_icdf_table.argtypes = [_f32p]
+        L.mco_icdf_table.restype = None
         L.mco_step_normals.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, _f32p]
         L.mco_step_normals.restype = None
-        L.mco_tables.argtypes = [_f32p, _f32p]
-        L.mco_tables.restype = None
         L.mco_simulate.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                    _f32p, _f32p, _f32p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                    _f32p, ctypes.c_int]
@@ -51,21 +51,19 @@ def philox4x32_10(ctr, key) -> np.ndarray:
     return out
 
 
-def box_muller(xa, xb):
-    xa = np.ascontiguousarray(xa, np.uint32)
-    xb = np.ascontiguousarray(xb, np.uint32)
-    zs = np.empty(xa.shape, np.float32)
-    zc = np.empty(xa.shape, np.float32)
-    lib().mco_box_muller_n(xa, xb, zs, zc, xa.size)
-    return zs, zc
+def normals(x) -> np.ndarray:
+    """N(0,1) draws of 32-bit words (SPEC.md section 3: inverse CDF)."""
+    x = np.ascontiguousarray(x, np.uint32)
+    z = np.empty(x.shape, np.float32)
+    lib().mco_normals_n(x, z, x.size)
+    return z
 
 
-def tables():
-    """(SC [1024,2], LG [1024,2]) float32 tables of SPEC.md section 3."""
-    sc = np.zeros((1024, 2), np.float32)
-    lg = np.zeros((1024, 2), np.float32)
-    lib().mco_tables(sc, lg)
-    return sc, lg
+def icdf_table() -> np.ndarray:
+    """[1056, 4] float32 coefficient table of SPEC.md section 3."""
+    t = np.zeros((1056, 4), np.float32)
+    lib().mco_icdf_table(t)
+    return t
 
 
 def step_normals(seed: int, path: int, step: int, n_assets: int) -> np.ndarray:

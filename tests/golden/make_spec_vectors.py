@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Freeze SPEC.md (version 3) as data: vectors produced by the CPU oracle, committed so that any later
+"""Freeze SPEC.md (version 4) as data: vectors produced by the CPU oracle, committed so that any later
 change of either implementation that moves a bit is caught on CPU (oracle) and on the GPU (kernels).
 
     python tests/golden/make_spec_vectors.py        # rewrites tests/golden/spec_vectors.npz
 
-Contents: the Box-Muller tables, the first 4,096 normals of path 0 (16 assets x 256 steps, seed
-0x5EED5EED), Box-Muller outputs for fixed edge inputs, terminal values of three small problems.
+Contents: the inverse-CDF table, the first 4,096 normals of path 0 (16 assets x 256 steps, seed
+0x5EED5EED), normals of fixed edge + random words, terminal values of three small problems.
 """
 import os
 import sys
@@ -29,14 +29,12 @@ def problem(N, K):
 
 def main():
     out = {}
-    sc, lg = mc_oracle.tables()
-    out["table_sincos"], out["table_log"] = sc, lg
+    out["icdf_table"] = mc_oracle.icdf_table()
     out["normals_path0"] = np.stack([mc_oracle.step_normals(SEED, 0, t, 16) for t in range(256)])
     e = np.array([0, 1, 2, 0xffffffff, 0xfffffffe, 0xffffff80, 0xffffff7f, 0x7fffffff, 0x80000000, 0x3fffffff, 0x40000000,
-                  0x001fffff, 0x00200000, 0x003fffff, 0x00400000, 0xbfffffff, 0xc0000000, 0x12345678, 0x9abcdef0], np.uint32)
-    A, B = [v.ravel().copy() for v in np.meshgrid(e, e)]
-    out["bm_xa"], out["bm_xb"] = A, B
-    out["bm_sin"], out["bm_cos"] = mc_oracle.box_muller(A, B)
+                  0x0003ffff, 0x00040000, 0x1fffffff, 0x20000000, 0xbfffffff, 0xc0000000, 0x12345678, 0x9abcdef0], np.uint32)
+    x = np.concatenate([e, np.random.default_rng(7).integers(0, 2 ** 32, 4096, dtype=np.uint32)])
+    out["normal_x"], out["normal_z"] = x, mc_oracle.normals(x)
     for tag, (N, K, T, P, pb, comp) in {"n16": (16, 1, 252, 512, 0, "simple"), "n3k5": (3, 5, 40, 300, (1 << 32) - 100, "simple"),
                                         "n64log": (64, 2, 6, 128, 7, "log")}.items():
         mu, L, W = problem(N, K)

@@ -3,7 +3,7 @@
 Philox4x32-10: Random123 known-answer vectors (kat_vectors of the Random123 distribution, the
 library rocRAND's engine cites at rocrand_philox4x32_10.h:287) and, when the ROCm headers and a
 host compiler are present, rocRAND's own host-callable engine.
-Box-Muller: against float64 math on the spec's u, and distribution moments.
+Normal transform (inverse CDF): against float64 scipy.special.ndtri on the spec's u, symmetry, monotonicity, moments.
 """
 import os
 import shutil
@@ -65,34 +65,35 @@ def test_philox_matches_rocrand_host_engine(oracle, tmp_path):
     assert n == 18
 
 
-def _math_reference(xa, xb):
-    u = (xa.astype(np.float32) * np.float32(2.0 ** -32) + np.float32(2.0 ** -32)).astype(np.float64)
-    s = np.sqrt(-2.0 * np.log(u))
-    th = 2.0 * np.pi * xb.astype(np.float64) / 2.0 ** 32
-    return s * np.sin(th), s * np.cos(th), s
+def _math_reference(x):
+    """-/+ Phi^-1(u) in float64 on the spec's u (scipy.special.ndtri), sign from bit 31."""
+    from scipy.special import ndtri
+    u = ((x & np.uint32(0x7fffffff)).astype(np.float32) * np.float32(2.0 ** -32) + np.float32(2.0 ** -33)).astype(np.float64)
+    return np.where(x >> np.uint32(31), ndtri(u), -ndtri(u)), u
 
 
-def test_box_muller_accuracy_vs_float64_math(oracle):
+def test_normal_transform_accuracy_vs_float64_math(oracle):
     rng = np.random.default_rng(1)
-    xa = rng.integers(0, 2 ** 32, 1_000_000, dtype=np.uint32)
-    xb = rng.integers(0, 2 ** 32, 1_000_000, dtype=np.uint32)
-    zs, zc = oracle.box_muller(xa, xb)
-    rs, rc, s = _math_reference(xa, xb)
-    scale = np.maximum(s, 1.0)
-    assert np.max(np.abs(zs - rs) / scale) < 4e-7     # fp32-grade: ~3 ulp of max(|z|, 1)
-    assert np.max(np.abs(zc - rc) / scale) < 4e-7
+    x = rng.integers(0, 2 ** 32, 2_000_000, dtype=np.uint32)
+    x[:100_000] = rng.integers(0, 1 << 12, 100_000).astype(np.uint32)                       # deepest positive tail
+    x[100_000:200_000] = np.uint32(0xffffffff) - rng.integers(0, 1 << 12, 100_000).astype(np.uint32)   # centre, negative side
+    z = oracle.normals(x)
+    want, u = _math_reference(x)
+    assert np.max(np.abs(z - want) / np.maximum(np.abs(want), 1.0)) < 2.5e-7       # fp32-grade everywhere, tails included
 
 
-def test_box_muller_edges(oracle):
-    e = np.array([0, 1, 2, 0xffffffff, 0xfffffffe, 0x7fffffff, 0x80000000, 0x3fffffff, 0x40000000,
-                  0x1fffffff, 0x20000000, 0xdfffffff, 0xe0000000, 0x5fffffff, 0x60000000], np.uint32)
-    A, B = [v.ravel().copy() for v in np.meshgrid(e, e)]
-    zs, zc = oracle.box_muller(A, B)
-    rs, rc, s = _math_reference(A, B)
-    assert np.isfinite(zs).all() and np.isfinite(zc).all()
-    assert np.max(np.abs(zs - rs)) < 1e-6 and np.max(np.abs(zc - rc)) < 1e-6
-    # u == 1.0 (xa = 0xffffffff rounds up): radius exactly 0
-    assert np.all(zs[A == 0xffffffff] == 0) and np.all(zc[A == 0xffffffff] == 0)
+def test_normal_transform_edges(oracle):
+    e = np.array([0, 1, 2, 0x7fffffff, 0x7ffffffe, 0x7fffff80, 0x7fffff7f, 0x40000000, 0x3fffffff, 0x20000000, 0x1fffffff,
+                  0x00040000, 0x0003ffff, 0x00000100, 0x000000ff], np.uint32)
+    x = np.concatenate([e, e | np.uint32(0x80000000)])
+    z = oracle.normals(x)
+    want, u = _math_reference(x)
+    assert np.isfinite(z).all() and np.max(np.abs(z - want)) < 6e-7
+    assert np.array_equal(z[:e.size], -z[e.size:])                         # exact symmetry: bit 31 is only the sign
+    assert z[3] == 0.0 and z[0] == np.float32(6.337958)                    # u == 1/2 -> 0 ; u = 2^-33 -> the largest draw
+    # monotone within the positive half: larger v (larger u) -> smaller magnitude
+    v = np.sort(np.random.default_rng(2).integers(0, 2 ** 31, 200_000, dtype=np.uint32))
+    assert np.all(np.diff(oracle.normals(v)) <= 2e-7)
 
 
 def test_normals_moments(oracle):
@@ -111,10 +112,9 @@ def test_normal_layout(oracle):
     assert z.size == 12
     for q in range(nb):
         x = oracle.philox4x32_10([t * nb + q, 0, p & 0xffffffff, p >> 32], [seed & 0xffffffff, seed >> 32])
-        s0, c0 = oracle.box_muller(x[0:1], x[1:2])
-        s1, c1 = oracle.box_muller(x[2:3], x[3:4])
-        assert z[0 * nb + q] == s0[0] and z[1 * nb + q] == c0[0]
-        assert z[2 * nb + q] == s1[0] and z[3 * nb + q] == c1[0]
+        zz = oracle.normals(x)
+        for m in range(4):
+            assert z[m * nb + q] == zz[m]
 
 
 def test_simulate_python_restatement(oracle):

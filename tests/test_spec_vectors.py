@@ -1,4 +1,4 @@
-"""SPEC.md version 3 frozen as data (tests/golden/spec_vectors.npz, written by make_spec_vectors.py from the
+"""SPEC.md version 4 frozen as data (tests/golden/spec_vectors.npz, written by make_spec_vectors.py from the
 oracle): the oracle must still reproduce it (CPU), and the HIP kernels must reproduce it (GPU)."""
 import os
 import sys
@@ -20,12 +20,10 @@ CASES = [t[len("terminal_"):] for t in V.files if t.startswith("terminal_")]
 
 
 def test_oracle_reproduces_the_frozen_vectors(oracle):
-    sc, lg = oracle.tables()
-    assert same_bits(sc, V["table_sincos"]) and same_bits(lg, V["table_log"])
+    assert same_bits(oracle.icdf_table(), V["icdf_table"])
     got = np.stack([oracle.step_normals(SEED, 0, t, 16) for t in range(256)])
     assert same_bits(got, V["normals_path0"]) and got.size == 4096
-    s, c = oracle.box_muller(V["bm_xa"], V["bm_xb"])
-    assert same_bits(s, V["bm_sin"]) and same_bits(c, V["bm_cos"])
+    assert same_bits(oracle.normals(V["normal_x"]), V["normal_z"])
     for tag in CASES:
         N, K, T, P, pb, log = [int(x) for x in V[f"params_{tag}"]]
         mu, L, W = problem(N, K)
@@ -33,14 +31,20 @@ def test_oracle_reproduces_the_frozen_vectors(oracle):
                          V[f"terminal_{tag}"]), tag
 
 
-def test_table_properties():
-    sc, lg = V["table_sincos"], V["table_log"]
-    th = 2 * np.pi * (np.arange(1024) + 0.5) / 1024
-    assert np.max(np.abs(sc[:, 0] - np.sin(th))) < 1e-7 and np.max(np.abs(sc[:, 1] - np.cos(th))) < 1e-7
-    assert lg[599, 0] == 1.0 and lg[599, 1] == 0.0
-    inv_c = lg[:, 0].astype(np.float64)
-    assert np.max(np.abs(lg[:, 1] - (-2 * np.log(1 / inv_c)))) < 5e-8
-    assert np.all(np.diff(lg[:, 1]) < 0)                       # -2 ln c decreases with the bin index
+def test_table_properties(mcp_lib):
+    """The table is DATA of the spec: the library's copy, the oracle's copy and the frozen copy are one and the same;
+    entry (E, j) evaluated at its centre is -Phi^-1 of the bin's centre."""
+    from scipy.special import ndtri
+    from monte_carlo_portfolio_amd import _ffi
+    T = V["icdf_table"]
+    lib_t = np.zeros((1056, 4), np.float32)
+    _ffi.check(mcp_lib.mcp_icdf_table(lib_t, lib_t.size))
+    assert same_bits(lib_t, T)
+    E, j = np.divmod(np.arange(1024), 32)
+    centre = 2.0 ** (E + 94 - 127) * (1.0 + j / 32.0 + 1.0 / 64.0)
+    assert np.max(np.abs(T[:1024, 0] - (-ndtri(centre))) / np.maximum(1.0, T[:1024, 0])) < 1e-7
+    assert np.all(T[1024:] == 0)                              # u == 1/2 -> exactly 0; the rest of octave 126 is unreachable
+    assert np.all(np.diff(T[:1024, 0]) < 0)                  # magnitude decreases as u grows
 
 
 @pytest.mark.gpu
@@ -59,15 +63,14 @@ def test_gpu_reproduces_the_frozen_terminal_values(gpu_ctx, tag):
 
 
 @pytest.mark.gpu
-def test_gpu_box_muller_reproduces_the_frozen_vectors(gpu_ctx):
+def test_gpu_normals_reproduce_the_frozen_vectors(gpu_ctx):
     import ctypes
     import torch
     from monte_carlo_portfolio_amd import _ffi
-    xa, xb = V["bm_xa"], V["bm_xb"]
-    n = xa.size
-    d_xa, d_xb = torch.from_numpy(xa.view(np.int32)).cuda(), torch.from_numpy(xb.view(np.int32)).cuda()
-    zs, zc = torch.empty(n, dtype=torch.float32, device="cuda"), torch.empty(n, dtype=torch.float32, device="cuda")
-    _ffi.check(_ffi.lib().mcp_launch_box_muller(d_xa.data_ptr(), d_xb.data_ptr(), n, zs.data_ptr(), zc.data_ptr(), 0,
-                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    x = V["normal_x"]
+    d_x = torch.from_numpy(x.view(np.int32)).cuda()
+    z = torch.empty(x.size, dtype=torch.float32, device="cuda")
+    _ffi.check(_ffi.lib().mcp_launch_normals(d_x.data_ptr(), x.size, z.data_ptr(),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
-    assert same_bits(zs.cpu().numpy(), V["bm_sin"]) and same_bits(zc.cpu().numpy(), V["bm_cos"])
+    assert same_bits(z.cpu().numpy(), V["normal_z"])
