@@ -7,7 +7,7 @@ abs-err vs the oracle), one process per GPU.
          bench.py --gpus N --steps K --warmup W
 
 A "step" is one full pass of the hot path over one batch resident in HBM: fused path kernel
-(Philox -> Box-Muller -> Cholesky GEMV -> compounding) for BASELINE configs[1] per GPU (16 synthetic
+(Philox -> inverse-CDF normals -> Cholesky GEMV -> compounding) for BASELINE configs[1] per GPU (16 synthetic
 assets, 1,000,000 paths, 252 steps, fp32), then moments, exact VaR (3-pass radix select) and CVaR,
 with the cross-rank exchanges of SURVEY.md section 8(e) when N > 1.  Weak scaling: every rank simulates its
 own 1M-path shard of one global path range.  Steps are independent batches; PathEngine double-buffers them
@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--native-math", action="store_true", help="hardware log/sqrt/sin/cos Box-Muller (tolerance parity)")
+    ap.add_argument("--native-math", action="store_true", help="normals by hardware log/sqrt/sin/cos Box-Muller (not the spec's values)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true",
                     help="side benchmark, NOT the BASELINE metric: configs[4] shape (10,000 Dirichlet portfolios, 16 assets, "
@@ -169,7 +169,8 @@ def main():
         nk_ms = ev0.elapsed_time(ev1) / n_k
         native = {"kernel_ms": nk_ms, "kernel_paths_per_s": PATHS_PER_GPU / (nk_ms * 1e-3),
                   "frac": PATHS_PER_GPU / (nk_ms * 1e-3) / VALU_CEILING_PATHS_PER_S,
-                  "note": "MCP_FLAG_NATIVE_MATH: v_log/v_sqrt/v_sin/v_cos Box-Muller, tolerance parity (SPEC.md section 6)"}
+                  "note": "MCP_FLAG_NATIVE_MATH: normals by v_log/v_sqrt/v_sin/v_cos Box-Muller (the mix the ceiling is priced on); "
+                          "same distribution, other values than the spec"}
 
     if rank == 0:
         total_paths = PATHS_PER_GPU * world * args.steps
@@ -195,8 +196,8 @@ def main():
             "note": "VALU-issue bound (SURVEY 0.4/8d): achieved/peak = model fp32 FLOPs (77,112/path) x paths/s; "
                     "peak = issue-cycle ceiling of the cheapest instruction mix for this algorithm at issue costs "
                     "measured on gfx950 (1,332 cycles per wave-step, DESIGN.md section 4), not the 157.3 TFLOP/s fp32 "
-                    "vector peak; the exact-math kernel executes table-driven Box-Muller (bit-reproducible) instead of "
-                    "hardware transcendentals",
+                    "vector peak; the spec's kernel draws its normals by a table-driven inverse CDF (bit-reproducible, 12 VALU "
+                    "ops per normal) instead of hardware-transcendental Box-Muller",
             "native_math_kernel": native,
             "frac_of_fp32_vector_peak": MODEL_FLOPS_PER_PATH * k_paths_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
             "hbm": {"achieved": HBM_BYTES_PER_PATH * k_paths_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
