@@ -450,3 +450,20 @@ def test_randomised_configurations_bit_exact(gpu_ctx):
         want = ref_stats.path_stats(ref[k], compounding=comp)
         assert got[0][k]["n"] == P and got[0][k]["n_tail"] == want["n_tail"]
         assert got[0][k]["var"] == pytest.approx(want["var"], rel=1e-12, abs=1e-15)
+
+
+def test_normal_transform_integrates_to_unit_variance(gpu_ctx):
+    """A regular grid of 2^27 words per sign (every 16th value of v) pushed through the device transform is a
+    midpoint quadrature of the moments of N(0,1): mean 0 (exact by symmetry), variance 1, fourth moment 3."""
+    import ctypes
+    import torch
+    n = 1 << 27
+    v = torch.arange(n, dtype=torch.int64, device="cuda") * 16 + 8
+    z = torch.empty(n, dtype=torch.float32, device="cuda")
+    _ffi.check(_ffi.lib().mcp_launch_normals(v.to(torch.int32).data_ptr(), n, z.data_ptr(),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    z64 = z.double()
+    m2 = float((z64 * z64).mean())
+    m4 = float((z64 ** 4).mean())
+    assert float(z.min()) >= 0.0 and abs(m2 - 1.0) < 2e-6 and abs(m4 - 3.0) < 3e-5     # positive half; the other is its mirror
