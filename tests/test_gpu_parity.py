@@ -364,7 +364,7 @@ def test_enqueue_only_steps_capture_into_a_hip_graph(gpu_ctx):
     mu, cov = synthetic.synthetic_market(N)
     mu32, L, W32 = prepare_inputs(mu, cov, synthetic.dirichlet_weights(N, 3))
     eng = PathEngine(mu32, L, W32, T, P, pipeline=False)
-    eng.step(SEED)                                  # warm-up: builds the per-device Box-Muller tables outside capture
+    eng.step(SEED)                                  # warm-up: uploads the per-device inverse-CDF table outside capture
     want = eng.stats()
     term = eng.terminal().copy()
     eng.d_terminal.zero_()
