@@ -58,6 +58,7 @@ def cpu_baseline(mu32, L, W32, seed):
 
 
 def main():
+    global PATHS_PER_GPU
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -68,7 +69,11 @@ def main():
                     help="side benchmark, NOT the BASELINE metric: configs[4] shape (10,000 Dirichlet portfolios, 16 assets, "
                          "252 steps, --sweep-paths paths), portfolio-sharded over the ranks, MFMA kernel")
     ap.add_argument("--sweep-paths", type=int, default=131072)
+    ap.add_argument("--paths-per-gpu", type=int, default=PATHS_PER_GPU,
+                    help="default 1,000,000 = BASELINE configs[1]; 12,500,000 is one GPU's shard of configs[2]")
     args = ap.parse_args()
+
+    PATHS_PER_GPU = args.paths_per_gpu
 
     import torch
     import torch.distributed as dist
@@ -208,7 +213,7 @@ def main():
             "value": value, "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: 16 synthetic assets, 1,000,000 paths per GPU, 252 steps, fp32, "
+            "config": {"workload": f"configs[1]: 16 synthetic assets, {PATHS_PER_GPU:,} paths per GPU, 252 steps, fp32, "
                                    "full pass = paths + moments + exact VaR/CVaR",
                        "n_assets": N_ASSETS, "n_steps": N_STEPS, "paths_per_gpu": PATHS_PER_GPU,
                        "global_paths": PATHS_PER_GPU * world, "parallelism": f"path-sharded x{world}",
