@@ -18,7 +18,7 @@
 #include "mcp_device.h"
 
 #ifndef MCP_MIN_WAVES
-#define MCP_MIN_WAVES 7     // __launch_bounds__ 2nd argument for N <= 16, one portfolio: caps the kernel at 64 VGPRs (8 waves/SIMD) without spills
+#define MCP_MIN_WAVES 7     // __launch_bounds__ 2nd argument for N <= 16, one portfolio: at least 7 waves/SIMD (<= 72 VGPRs, no spills)
 #endif
 #ifndef MCP_EXP_VKEYS
 #define MCP_EXP_VKEYS 1
@@ -163,7 +163,6 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
       }
     }
   }
-
 }
 
 }  // namespace mcp
