@@ -100,6 +100,9 @@ def simulate_paths(mu, cov, weights, n_steps=252, n_paths=10_000, seed=0, v0=1.0
     single = np.asarray(weights).ndim == 1
     mu32, L, W = prepare_inputs(mu, cov, weights, chol)
     prm = _ffi.make_params(mu32.shape[0], n_steps, W.shape[0], compounding, v0, alpha, rf, native_math)
+    if devices is not None and len(devices) > 1:
+        raise NotImplementedError("simulate_paths drives ONE GPU per call; for several GPUs run one process per GPU with "
+                                  "engine.PathEngine (torch.distributed / RCCL), see INTEGRATION.md section 4")
     dev = 0 if not devices else int(devices[0])
     stats, term = default_context(dev).simulate(prm, mu32, L, W, int(seed), int(path_begin), int(n_paths), store)
     if as_array:                      # [K] structured array (fields of mcp_stats), for large sweeps

@@ -177,3 +177,9 @@ def test_header_is_valid_c99_and_links_from_c(tmp_path, mcp_lib):
     lo, hi, g = out.stdout.split()[:3]
     assert (int(lo), int(hi)) == (49999, 50000) and float(g) == _ffi.percentile_rank(1_000_000, 0.95)[2]
     assert "NULL device pointer" in out.stdout
+
+
+def test_multi_device_request_is_refused_not_ignored():
+    from monte_carlo_portfolio_amd import simulate_paths
+    with pytest.raises(NotImplementedError, match="one process per GPU"):
+        simulate_paths(np.zeros(3), np.eye(3) * 1e-4, np.ones(3) / 3, n_paths=8, devices=[0, 1])
