@@ -130,6 +130,7 @@ def main():
                      native_math=args.native_math)
 
     def sync():
+        torch.cuda.synchronize()          # all three pipeline streams drained before the cross-rank barrier is issued
         if group is not None:
             dist.barrier()
         torch.cuda.synchronize()
