@@ -114,22 +114,24 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
     }
 }
 
-// ---- shared-draw variant: the four waves of a workgroup own the SAME 64 paths and 4 x 128 = 512 portfolios.
+// ---- shared-draw variant: the four waves of a workgroup own the SAME 64 paths and 4 x 32 MT portfolios.
 // The per-step draw is split four ways and exchanged through LDS: wave w runs Philox blocks q = w, w+4, ...
 // and their normals (z rows to LDS), then row pairs m = w, w+4, ... of the GEMV (r rows to LDS); after
 // the second barrier every wave reads its MFMA B operands straight from the r image (lane l: r[2kk + (l>>5)]
-// [32nt + (l&31)], conflict-free), so no permlane is needed.  Two barriers per step, z/r double-buffered by the
-// parity of t.  Same arithmetic, same order: bit-identical to mc_sweep_kernel and to the oracle.
-template <int NB, bool NATIVE, bool LOGC>
+// [32nt + (l&31)], conflict-free), so no permlane is needed.  Two barriers per step suffice without double buffering:
+// z(t+1) is written after barrier 2 of step t (all reads of z(t) precede it), r(t+1) after barrier 1 of step t+1
+// (every wave loads its B operands of step t before reaching it).  Same arithmetic, same order: bit-identical to
+// mc_sweep_kernel and to the oracle.  MT = 4 (512 portfolios per workgroup) for N <= 16, MT = 2 (256) up to N = 64.
+template <int NB, int MT, bool NATIVE, bool LOGC>
 __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const PathArgs a) {
-  constexpr int N4 = 4 * NB, KS = N4 / 2, MT = 4;
+  constexpr int N4 = 4 * NB, KS = N4 / 2;
   typedef const __attribute__((address_space(4))) float* cfloat_p;
   cfloat_p mu = (cfloat_p)a.packed;
   cfloat_p Lp = mu + N4;
   const float* __restrict__ Wg = a.packed + N4 + N4 * (N4 / 2 + 1);
 
   __shared__ float4 s_tab[ICDF_ENTRIES];
-  __shared__ float s_z[2][N4][64], s_r[2][N4][64];
+  __shared__ float s_z[N4][64], s_r[N4][64];
   if constexpr (!NATIVE) {
     for (int i = threadIdx.x; i < ICDF_ENTRIES; i += PATH_BLOCK) s_tab[i] = a.tables[i];
   }
@@ -159,7 +161,6 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
 
   for (int t = 0; t < a.n_steps; t++) {
     asm volatile("" : "+s"(mu), "+s"(Lp));
-    const int buf = t & 1;
     // phase A: this wave's share of the normals
 #pragma unroll
     for (int q0 = 0; q0 < NB; q0 += 4) {
@@ -169,10 +170,10 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
         philox4x32_10((uint32_t)t * NB + q, 0u, plo, phi, ks, x);
         float z0, z1, z2, z3;
         block_normals<NATIVE>(x, s_tab, z0, z1, z2, z3);
-        s_z[buf][0 * NB + q][lane] = z0;
-        s_z[buf][1 * NB + q][lane] = z1;
-        s_z[buf][2 * NB + q][lane] = z2;
-        s_z[buf][3 * NB + q][lane] = z3;
+        s_z[0 * NB + q][lane] = z0;
+        s_z[1 * NB + q][lane] = z1;
+        s_z[2 * NB + q][lane] = z2;
+        s_z[3 * NB + q][lane] = z3;
       }
     }
     __syncthreads();
@@ -187,11 +188,11 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
 #pragma unroll
           for (int j = 0; j <= 2 * m + 1; j++) {
             const f32x2 l2 = {Lp[2 * m * (m + 1) + 2 * j], Lp[2 * m * (m + 1) + 2 * j + 1]};
-            const float zj = s_z[buf][j][lane];
+            const float zj = s_z[j][lane];
             acc = __builtin_elementwise_fma(l2, (f32x2){zj, zj}, acc);
           }
-          s_r[buf][2 * m][lane] = acc.x;
-          s_r[buf][2 * m + 1][lane] = acc.y;
+          s_r[2 * m][lane] = acc.x;
+          s_r[2 * m + 1][lane] = acc.y;
         }
       }
     }
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-      for (int kk = 0; kk < KS; kk++) b[nt][kk] = s_r[buf][2 * kk + (lane >> 5)][32 * nt + (lane & 31)];
+      for (int kk = 0; kk < KS; kk++) b[nt][kk] = s_r[2 * kk + (lane >> 5)][32 * nt + (lane & 31)];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
@@ -231,20 +232,21 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
 
 template <int NB>
 static hipError_t go_shared(bool native, const PathArgs& args, hipStream_t stream) {
-  const dim3 grid((unsigned)((args.n_paths + 63) / 64), (unsigned)((args.n_portfolios + 511) / 512));
+  constexpr int MT = NB <= 4 ? 4 : 2;
+  const dim3 grid((unsigned)((args.n_paths + 63) / 64), (unsigned)((args.n_portfolios + 128 * MT - 1) / (128 * MT)));
   const bool lg = args.compounding == MCP_COMPOUND_LOG;
-  if (native) { if (lg) mc_sweep_shared_kernel<NB, true, true><<<grid, PATH_BLOCK, 0, stream>>>(args); else mc_sweep_shared_kernel<NB, true, false><<<grid, PATH_BLOCK, 0, stream>>>(args); }
-  else { if (lg) mc_sweep_shared_kernel<NB, false, true><<<grid, PATH_BLOCK, 0, stream>>>(args); else mc_sweep_shared_kernel<NB, false, false><<<grid, PATH_BLOCK, 0, stream>>>(args); }
+  if (native) { if (lg) mc_sweep_shared_kernel<NB, MT, true, true><<<grid, PATH_BLOCK, 0, stream>>>(args); else mc_sweep_shared_kernel<NB, MT, true, false><<<grid, PATH_BLOCK, 0, stream>>>(args); }
+  else { if (lg) mc_sweep_shared_kernel<NB, MT, false, true><<<grid, PATH_BLOCK, 0, stream>>>(args); else mc_sweep_shared_kernel<NB, MT, false, false><<<grid, PATH_BLOCK, 0, stream>>>(args); }
   return hipGetLastError();
 }
 
 // K rows of W must be zero-padded to a multiple of 512 (mcp_pack_params pads to K_PAD).
 hipError_t launch_sweep_shared(int nb, bool native, const PathArgs& args, hipStream_t stream) {
   switch (nb) {
-    case 1: return go_shared<1>(native, args, stream);
-    case 2: return go_shared<2>(native, args, stream);
-    case 3: return go_shared<3>(native, args, stream);
-    case 4: return go_shared<4>(native, args, stream);
+#define MCP_CASE(n) case n: return go_shared<n>(native, args, stream);
+    MCP_CASE(1) MCP_CASE(2) MCP_CASE(3) MCP_CASE(4) MCP_CASE(5) MCP_CASE(6) MCP_CASE(7) MCP_CASE(8)
+    MCP_CASE(9) MCP_CASE(10) MCP_CASE(11) MCP_CASE(12) MCP_CASE(13) MCP_CASE(14) MCP_CASE(15) MCP_CASE(16)
+#undef MCP_CASE
     default: return hipErrorInvalidValue;
   }
 }

@@ -217,7 +217,8 @@ def test_path_engine_two_ranks_on_one_gpu(gpu_ctx, tmp_path):
 @pytest.mark.parametrize("N,K,P,T,comp", [(16, 17, 4000, 30, "simple"), (16, 130, 3000, 25, "simple"), (16, 300, 1100, 12, "log"),
                                           (12, 64, 2049, 20, "simple"), (3, 40, 1000, 15, "simple"),
                                           (16, 384, 300, 10, "simple"), (16, 700, 257, 8, "log"), (10, 513, 130, 6, "simple"),
-                                          (4, 400, 100, 9, "simple")])
+                                          (4, 400, 100, 9, "simple"), (32, 40, 700, 9, "simple"), (64, 300, 200, 5, "log"),
+                                          (20, 17, 1000, 11, "simple"), (61, 257, 130, 4, "simple")])
 def test_mfma_sweep_kernel_bit_exact(gpu_ctx, N, K, P, T, comp):
     """K >= 17, N <= 16 runs mc_sweep_kernel (W.r on v_mfma_f32_32x32x2_f32): same bits as the oracle's fma chain."""
     got, ref = run_both(N, T, P, K=K, compounding=comp, rf=0.0005)
