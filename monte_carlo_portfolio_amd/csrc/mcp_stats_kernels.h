@@ -35,6 +35,10 @@ MCP_DECL_NB(9) MCP_DECL_NB(10) MCP_DECL_NB(11) MCP_DECL_NB(12) MCP_DECL_NB(13) M
 
 // mcp_sweep_paths.hip: MFMA K-portfolio kernel (N <= 16); mt = 32-portfolio tiles per wave (1, 2 or 4)
 hipError_t launch_sweep_shared(int nb, bool native, const PathArgs& args, hipStream_t stream);
+hipError_t launch_sweep_shared_p0(int nb, bool native, const PathArgs& args, hipStream_t stream);
+hipError_t launch_sweep_shared_p1(int nb, bool native, const PathArgs& args, hipStream_t stream);
+hipError_t launch_sweep_shared_p2(int nb, bool native, const PathArgs& args, hipStream_t stream);
+hipError_t launch_sweep_shared_p3(int nb, bool native, const PathArgs& args, hipStream_t stream);
 hipError_t launch_sweep_paths(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream);
 hipError_t launch_normals(const uint32_t* x, uint64_t n, const float4* table, float* z, hipStream_t s);
 hipError_t launch_moments(const mcp_params& prm, int K, const float* terminal, uint64_t stride, uint64_t n,

@@ -17,10 +17,17 @@
 #include "mcp_paths.h"
 #include "mcp_stats_kernels.h"
 
+#ifndef MCP_SWEEP_PART
+#error "compile with -DMCP_SWEEP_PART=<0..3> (part p instantiates the shared-draw kernel for NB = 4p+1 .. 4p+4)"
+#endif
+#define MCP_CAT_(a, b) a##b
+#define MCP_CAT(a, b) MCP_CAT_(a, b)
+
 namespace mcp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#if MCP_SWEEP_PART == 0
 template <int NB, int MT, bool NATIVE, bool LOGC>
 __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs a) {
   constexpr int N4 = 4 * NB, KS = N4 / 2;   // KS k-steps of 2 assets
@@ -113,6 +120,8 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
       }
     }
 }
+
+#endif  // MCP_SWEEP_PART == 0
 
 // ---- shared-draw variant: the four waves of a workgroup own the SAME 64 paths and 4 x 32 MT portfolios.
 // The per-step draw is split four ways and exchanged through LDS: wave w runs Philox blocks q = w, w+4, ...
@@ -241,13 +250,31 @@ static hipError_t go_shared(bool native, const PathArgs& args, hipStream_t strea
 }
 
 // K rows of W must be zero-padded to a multiple of 512 (mcp_pack_params pads to K_PAD).
-hipError_t launch_sweep_shared(int nb, bool native, const PathArgs& args, hipStream_t stream) {
+hipError_t MCP_CAT(launch_sweep_shared_p, MCP_SWEEP_PART)(int nb, bool native, const PathArgs& args, hipStream_t stream) {
   switch (nb) {
 #define MCP_CASE(n) case n: return go_shared<n>(native, args, stream);
-    MCP_CASE(1) MCP_CASE(2) MCP_CASE(3) MCP_CASE(4) MCP_CASE(5) MCP_CASE(6) MCP_CASE(7) MCP_CASE(8)
-    MCP_CASE(9) MCP_CASE(10) MCP_CASE(11) MCP_CASE(12) MCP_CASE(13) MCP_CASE(14) MCP_CASE(15) MCP_CASE(16)
+#if MCP_SWEEP_PART == 0
+    MCP_CASE(1) MCP_CASE(2) MCP_CASE(3) MCP_CASE(4)
+#elif MCP_SWEEP_PART == 1
+    MCP_CASE(5) MCP_CASE(6) MCP_CASE(7) MCP_CASE(8)
+#elif MCP_SWEEP_PART == 2
+    MCP_CASE(9) MCP_CASE(10) MCP_CASE(11) MCP_CASE(12)
+#else
+    MCP_CASE(13) MCP_CASE(14) MCP_CASE(15) MCP_CASE(16)
+#endif
 #undef MCP_CASE
     default: return hipErrorInvalidValue;
+  }
+}
+
+#if MCP_SWEEP_PART == 0
+hipError_t launch_sweep_shared(int nb, bool native, const PathArgs& args, hipStream_t stream) {
+  if (nb < 1 || nb > 16) return hipErrorInvalidValue;
+  switch ((nb - 1) / 4) {
+    case 0: return launch_sweep_shared_p0(nb, native, args, stream);
+    case 1: return launch_sweep_shared_p1(nb, native, args, stream);
+    case 2: return launch_sweep_shared_p2(nb, native, args, stream);
+    default: return launch_sweep_shared_p3(nb, native, args, stream);
   }
 }
 
@@ -279,5 +306,7 @@ hipError_t launch_sweep_paths(int nb, int mt, bool native, const PathArgs& args,
     default: return hipErrorInvalidValue;
   }
 }
+
+#endif  // MCP_SWEEP_PART == 0
 
 }  // namespace mcp
