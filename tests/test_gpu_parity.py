@@ -468,3 +468,50 @@ def test_normal_transform_integrates_to_unit_variance(gpu_ctx):
     m2 = float((z64 * z64).mean())
     m4 = float((z64 ** 4).mean())
     assert float(z.min()) >= 0.0 and abs(m2 - 1.0) < 2e-6 and abs(m4 - 3.0) < 3e-5     # positive half; the other is its mirror
+
+
+PF_ENGINE_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+from monte_carlo_portfolio_amd import synthetic
+from monte_carlo_portfolio_amd.engine import PathEngine
+from monte_carlo_portfolio_amd.simulate import prepare_inputs
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+mu, cov = synthetic.synthetic_market(16)
+W = synthetic.dirichlet_weights(16, 45)                  # 45 portfolios over 2 ranks: 23 + 22
+mu32, L, W32 = prepare_inputs(mu, cov, W)
+eng = PathEngine(mu32, L, W32, 20, 6000, rf=0.001, group=dist.group.WORLD, world_size=world, rank=rank,
+                 shard="portfolios", pipeline=False)
+eng.step(seed=321)
+st = eng.gathered_stats()
+np.save({out!r} + str(rank) + ".npy", st)
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_portfolio_sharded_engine_two_ranks_on_one_gpu(gpu_ctx, tmp_path):
+    """configs[4] sharding with the real kernels: each of two processes walks all paths for its slice of W (MFMA
+    sweep kernel), one all_gather of the records; must equal one process scoring all 45 portfolios."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "pf_")
+    script = tmp_path / "pf_worker.py"
+    script.write_text(PF_ENGINE_WORKER.format(root=root, out=out))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        o, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, o.decode()[-3000:]
+    a, b = np.load(out + "0.npy"), np.load(out + "1.npy")
+    assert a.shape == (45,) and np.array_equal(a, b)
+    mu, cov = synthetic.synthetic_market(16)
+    W = synthetic.dirichlet_weights(16, 45)
+    want = simulate_paths(mu, cov, W, n_steps=20, n_paths=6000, seed=321, rf=0.001, as_array=True)
+    for key in want.dtype.names:
+        assert np.array_equal(a[key], want[key]), key
