@@ -41,9 +41,12 @@ enum {
 };
 
 enum {
-    MCP_FLAG_NATIVE_MATH = 1   /* normals by Box-Muller on the v_log/v_sqrt/v_sin/v_cos hardware approximations instead
+    MCP_FLAG_NATIVE_MATH = 1,  /* normals by Box-Muller on the v_log/v_sqrt/v_sin/v_cos hardware approximations instead
                                   of the spec's inverse-CDF table: statistically equivalent draws from the same Philox
                                   stream, NOT comparable to the oracle value by value */
+    MCP_FLAG_FOLD = 2          /* one portfolio only: rho = w.mu + (L^T w).z with L^T w folded on the host (SPEC.md 4.1)
+                                  instead of the triangular GEMV + weight dot.  A separately reported fast path: same
+                                  normals, other rounding than the unfolded recurrence (agrees to ~1e-7 relative) */
 };
 
 typedef struct mcp_ctx mcp_ctx;
@@ -130,7 +133,7 @@ size_t mcp_ws_bytes(int which, int n_portfolios);
 
 /* Number of floats of the packed parameter block for (N, K). */
 size_t mcp_packed_len(int n_assets, int n_portfolios);
-/* Pack mu, lower(chol), W into the padded device layout (host side, no GPU needed). */
+/* Pack mu, lower(chol), W (and portfolio 0's fold block) into the padded device layout (host side, no GPU needed). */
 int mcp_pack_params(int n_assets, int n_portfolios, const float *mu, const float *chol, const float *W,
                     float *packed_out, size_t packed_len);
 

@@ -22,6 +22,7 @@ MCP_MAX_ASSETS = 64
 MCP_SELECT_BINS = 2048
 MCP_COMPOUND = {"simple": 0, "log": 1}
 MCP_FLAG_NATIVE_MATH = 1
+MCP_FLAG_FOLD = 2
 (WS_PARTIALS, WS_MOMENTS, WS_STATE, WS_HIST, WS_QUANT, WS_TAIL_PARTIAL, WS_TAIL, WS_STATS) = range(8)
 
 
@@ -149,11 +150,12 @@ def check(rc: int) -> int:
 
 
 def make_params(n_assets, n_steps, n_portfolios, compounding="simple", v0=1.0, alpha=0.95, rf=0.0,
-                native_math=False) -> McpParams:
+                native_math=False, fold=False) -> McpParams:
     if compounding not in MCP_COMPOUND:
         raise ValueError(f"compounding must be 'simple' or 'log', got {compounding!r}")
     return McpParams(int(n_assets), int(n_steps), int(n_portfolios), MCP_COMPOUND[compounding],
-                     MCP_FLAG_NATIVE_MATH if native_math else 0, 0, float(v0), float(alpha), float(rf))
+                     (MCP_FLAG_NATIVE_MATH if native_math else 0) | (MCP_FLAG_FOLD if fold else 0), 0,
+                     float(v0), float(alpha), float(rf))
 
 
 def pack_params(mu: np.ndarray, chol: np.ndarray, W: np.ndarray) -> np.ndarray:

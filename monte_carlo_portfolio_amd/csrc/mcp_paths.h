@@ -35,6 +35,7 @@ struct PathArgs {
   uint64_t seed, path_begin, n_paths, stride;
   int32_t n_steps, n_portfolios, k_begin, compounding;
   float v0;
+  uint32_t fold_offset;               // float index of [c, v_0 .. v_{N4-1}] (portfolio 0 folded through L, SPEC.md 4.1)
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -60,8 +61,9 @@ __device__ __forceinline__ double terminal_to_x(float term, double v0, int compo
 
 constexpr int PATH_BLOCK = 256;
 
-// NB = N4/4 Philox blocks per path-step; KT portfolios per pass; PPT paths per lane.
-template <int NB, int KT, int PPT, bool NATIVE>
+// NB = N4/4 Philox blocks per path-step; KT portfolios per pass; PPT paths per lane; FOLD: rho = c + v.z with
+// v = L^T w precomputed on the host (SPEC.md 4.1, one portfolio) instead of the triangular GEMV.
+template <int NB, int KT, int PPT, bool NATIVE, bool FOLD = false>
 __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ? MCP_MIN_WAVES : 1) mc_paths_kernel(const PathArgs a) {
   constexpr int N4 = 4 * NB;
   // wave-uniform parameters through the constant address space -> s_load_dword* into SGPRs
@@ -116,8 +118,19 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
           block_normals<NATIVE>(x, s_tab, z[e][0 * NB + q], z[e][1 * NB + q], z[e][2 * NB + q], z[e][3 * NB + q]);
         }
       }
-      // r = mu + L z (row i: acc = mu_i, then j ascending), rho_k = sum_i w_ki r_i (i ascending)
       float rho[PPT][KT];
+      if constexpr (FOLD) {
+        cfloat_p fv = mu + a.fold_offset;
+        asm volatile("" : "+s"(fv));
+#pragma unroll
+        for (int e = 0; e < PPT; e++) {
+          float acc = fv[0];
+#pragma unroll
+          for (int j = 0; j < N4; j++) acc = fma32(fv[1 + j], z[e][j], acc);
+          rho[e][0] = acc;
+        }
+      } else {
+      // r = mu + L z (row i: acc = mu_i, then j ascending), rho_k = sum_i w_ki r_i (i ascending)
 #pragma unroll
       for (int e = 0; e < PPT; e++)
 #pragma unroll
@@ -147,6 +160,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
           }
         }
       }
+      }  // !FOLD
 #pragma unroll
       for (int e = 0; e < PPT; e++)
 #pragma unroll

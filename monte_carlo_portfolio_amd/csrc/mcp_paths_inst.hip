@@ -32,6 +32,7 @@ hipError_t MCP_CAT(launch_paths_nb, MCP_NB)(int variant, const PathArgs& args, i
   switch (variant) {
     case 0: return go<1, 1, false>(args, grid, stream);
     case VAR_NATIVE: return go<1, 1, true>(args, grid, stream);
+    case VAR_FOLD: mc_paths_kernel<MCP_NB, 1, 1, false, true><<<grid, PATH_BLOCK, lds_pad(), stream>>>(args); return hipGetLastError();
     case VAR_KT8: return go<8, 1, false>(args, grid, stream);
     case VAR_KT8 | VAR_NATIVE: return go<8, 1, true>(args, grid, stream);
 #if MCP_NB <= 4 && defined(MCP_EXP_PPT2)      // two paths per lane: measured 3 % slower (129 VGPRs), kept behind a build flag

@@ -23,7 +23,7 @@ constexpr int MOMENTS_GRID = 256;
 struct PathArgs;
 
 // variant bits for launch_paths
-enum { VAR_KT8 = 1, VAR_PPT2 = 2, VAR_NATIVE = 4 };
+enum { VAR_KT8 = 1, VAR_PPT2 = 2, VAR_NATIVE = 4, VAR_FOLD = 8 };
 
 // mcp_paths_inst.hip (one translation unit per NB): returns hipErrorInvalidValue for a variant that
 // is not instantiated.

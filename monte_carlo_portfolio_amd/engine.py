@@ -82,7 +82,7 @@ class PathEngine:
 
     def __init__(self, mu32, chol32, W32, n_steps, n_paths_local, *, compounding="simple", v0=1.0, alpha=0.95,
                  rf=0.0, native_math=False, device=None, group=None, world_size=1, rank=0, kernels=None,
-                 pipeline=True, shard="paths", n_buffers=None):
+                 pipeline=True, shard="paths", n_buffers=None, fold=False):
         import torch
 
         self.torch = torch
@@ -110,7 +110,7 @@ class PathEngine:
         self.n_total = self.n_local * self.world
         K = W32.shape[0]
         self.K = K
-        self.prm = _ffi.make_params(mu32.shape[0], n_steps, K, compounding, v0, alpha, rf, native_math)
+        self.prm = _ffi.make_params(mu32.shape[0], n_steps, K, compounding, v0, alpha, rf, native_math, fold)
         self.rank_lo, self.rank_hi, self.gamma = _ffi.percentile_rank(self.n_total, alpha)
         self.pipeline = bool(pipeline) and self.device.type == "cuda"
         # in-flight batches: 2 hide the statistics tail on one GPU; with collectives in that tail (each one waits for

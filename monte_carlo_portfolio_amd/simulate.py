@@ -89,7 +89,7 @@ def stats_to_dict(rec) -> dict:
 
 def simulate_paths(mu, cov, weights, n_steps=252, n_paths=10_000, seed=0, v0=1.0, compounding="simple",
                    rf=0.0, alpha=0.95, devices=None, store=False, path_begin=0, chol=None,
-                   native_math=False, as_array=False):
+                   native_math=False, as_array=False, fold=False):
     """Simulate `n_paths` correlated return paths and reduce them to risk statistics.
 
     mu [N], cov [N,N] are per-step mean and covariance (the reference's `mean_returns`, `cov_matrix`
@@ -99,7 +99,7 @@ def simulate_paths(mu, cov, weights, n_steps=252, n_paths=10_000, seed=0, v0=1.0
     """
     single = np.asarray(weights).ndim == 1
     mu32, L, W = prepare_inputs(mu, cov, weights, chol)
-    prm = _ffi.make_params(mu32.shape[0], n_steps, W.shape[0], compounding, v0, alpha, rf, native_math)
+    prm = _ffi.make_params(mu32.shape[0], n_steps, W.shape[0], compounding, v0, alpha, rf, native_math, fold)
     if devices is not None and len(devices) > 1:
         raise NotImplementedError("simulate_paths drives ONE GPU per call; for several GPUs run one process per GPU with "
                                   "engine.PathEngine (torch.distributed / RCCL), see INTEGRATION.md section 4")

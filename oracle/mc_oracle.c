@@ -122,7 +122,7 @@ void mco_step_normals(uint64_t seed, uint64_t path, uint32_t step, int n_assets,
 
 /* ---- the path loop --------------------------------------------------------------------------- */
 typedef struct {
-    int n_assets, n_steps, n_portfolios, compounding;   /* compounding: 0 simple, 1 log-sum */
+    int n_assets, n_steps, n_portfolios, compounding;   /* compounding: 0 simple, 1 log-sum; +2: folded (SPEC.md 4.1) */
     float v0;
     const float *mu, *chol, *W;
     uint64_t seed, path_begin, n_paths, p_lo, p_hi;
@@ -148,11 +148,30 @@ static void simulate_range(const mco_job *j)
     for (int k = 0; k < K; k++)
         for (int i = 0; i < N; i++) Wp[k * N4 + i] = j->W[k * N + i];
 
+    const int fold = (j->compounding & 2) != 0, logc = (j->compounding & 1) != 0;
+    float fc = 0.0f, fv[MCO_MAX_ASSETS];
+    memset(fv, 0, sizeof fv);
+    if (fold) {                                            /* c = w.mu, v = L^T w in binary64, rounded once */
+        double c = 0.0;
+        for (int i = 0; i < N; i++) c += (double)j->W[i] * (double)mu[i];
+        fc = (float)c;
+        for (int col = 0; col < N; col++) {
+            double v = 0.0;
+            for (int i = col; i < N; i++) v += (double)j->W[i] * (double)j->chol[i * N + col];
+            fv[col] = (float)v;
+        }
+    }
     for (uint64_t p = j->p_lo; p < j->p_hi; p++) {
         const uint64_t path = j->path_begin + p;
-        for (int k = 0; k < K; k++) V[k] = j->compounding ? 0.0f : j->v0;
+        for (int k = 0; k < K; k++) V[k] = logc ? 0.0f : j->v0;
         for (int t = 0; t < T; t++) {
             step_normals(k0, k1, path, (uint32_t)t, nb, z);
+            if (fold) {                                     /* rho = c + v.z, j ascending, fma (one portfolio) */
+                float rho = fc;
+                for (int c = 0; c < N4; c++) rho = fmaf(fv[c], z[c], rho);
+                if (logc) V[0] = V[0] + rho; else V[0] = fmaf(V[0], rho, V[0]);
+                continue;
+            }
             for (int i = 0; i < N4; i++) {                  /* r = mu + L z, j ascending, fma */
                 float acc = mu[i];
                 for (int c = 0; c <= i; c++) acc = fmaf(L[i * N4 + c], z[c], acc);
@@ -161,7 +180,7 @@ static void simulate_range(const mco_job *j)
             for (int k = 0; k < K; k++) {                   /* rho = w . r, i ascending, fma */
                 float rho = 0.0f;
                 for (int i = 0; i < N4; i++) rho = fmaf(Wp[k * N4 + i], r[i], rho);
-                if (j->compounding) V[k] = V[k] + rho;      /* S += rho */
+                if (logc) V[k] = V[k] + rho;                /* S += rho */
                 else V[k] = fmaf(V[k], rho, V[k]);          /* V *= (1 + rho) */
             }
         }

@@ -73,7 +73,7 @@ def step_normals(seed: int, path: int, step: int, n_assets: int) -> np.ndarray:
 
 
 def simulate(mu, chol, W, n_steps: int, n_paths: int, seed: int, path_begin: int = 0, v0: float = 1.0,
-             compounding: str = "simple", n_threads: int | None = None) -> np.ndarray:
+             compounding: str = "simple", n_threads: int | None = None, fold: bool = False) -> np.ndarray:
     """Terminal values [K, n_paths] float32 (V_T for 'simple'; sum of rho for 'log')."""
     mu = np.ascontiguousarray(mu, np.float32)
     chol = np.ascontiguousarray(chol, np.float32)
@@ -84,7 +84,9 @@ def simulate(mu, chol, W, n_steps: int, n_paths: int, seed: int, path_begin: int
     out = np.empty((K, n_paths), np.float32)
     if n_threads is None:
         n_threads = min(os.cpu_count() or 1, 64)
-    rc = lib().mco_simulate(n, n_steps, K, {"simple": 0, "log": 1}[compounding], v0, mu, chol, W,
+    if fold and K != 1:
+        raise ValueError("fold needs exactly one portfolio")
+    rc = lib().mco_simulate(n, n_steps, K, {"simple": 0, "log": 1}[compounding] | (2 if fold else 0), v0, mu, chol, W,
                             seed, path_begin, n_paths, out, n_threads)
     if rc != 0:
         raise ValueError(f"mco_simulate failed rc={rc}")

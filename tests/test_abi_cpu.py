@@ -50,7 +50,7 @@ def test_pack_params_layout(mcp_lib):
     W = rng.normal(size=(K, N)).astype(np.float32)
     p = _ffi.pack_params(mu, L, W)
     n4 = 8
-    assert p.size == n4 + n4 * (n4 // 2 + 1) + 512 * n4 == mcp_lib.mcp_packed_len(N, K)
+    assert p.size == n4 + n4 * (n4 // 2 + 1) + 512 * n4 + 4 + n4 == mcp_lib.mcp_packed_len(N, K)
     assert np.array_equal(p[:N], mu) and not np.signbit(p[2]) and np.all(p[N:n4] == 0)
     Lp = p[n4:n4 + n4 * (n4 // 2 + 1)]
     for m in range(n4 // 2):                      # row pairs (2m, 2m+1), columns interleaved
@@ -59,7 +59,12 @@ def test_pack_params_layout(mcp_lib):
                 i = 2 * m + h
                 want = L[i, j] if (i < N and j <= i) else 0.0
                 assert Lp[2 * m * (m + 1) + 2 * j + h] == want
-    Wp = p[n4 + n4 * (n4 // 2 + 1):].reshape(512, n4)
+    Wp = p[n4 + n4 * (n4 // 2 + 1):n4 + n4 * (n4 // 2 + 1) + 512 * n4].reshape(512, n4)
+    F = p[n4 + n4 * (n4 // 2 + 1) + 512 * n4:]            # fold block of portfolio 0: [c, v_0..v_{n4-1}, pad]
+    Lt = np.tril(L).astype(np.float64)
+    assert F[0] == np.float32(np.dot(W[0].astype(np.float64), (mu + np.float32(0)).astype(np.float64)))
+    np.testing.assert_allclose(F[1:1 + N], (Lt.T @ W[0].astype(np.float64)).astype(np.float32), rtol=2e-7)
+    assert np.all(F[1 + N:] == 0)
     assert np.array_equal(Wp[:K, :N], W) and np.all(Wp[:K, N:] == 0) and np.all(Wp[K:] == 0)
 
 
@@ -160,7 +165,7 @@ def test_header_is_valid_c99_and_links_from_c(tmp_path, mcp_lib):
             uint64_t lo, hi; double g;
             if (mcp_abi_version() != MCP_ABI_VERSION) return 1;
             if (mcp_percentile_rank(1000000, p.alpha, &lo, &hi, &g) != MCP_OK) return 2;
-            if (mcp_packed_len(16, 1) != 16 + 16 * 9 + 512 * 16) return 3;
+            if (mcp_packed_len(16, 1) != 16 + 16 * 9 + 512 * 16 + 20) return 3;
             if (mcp_launch_paths(&p, NULL, 0, 0, 10, NULL, 10, NULL) != MCP_E_ARG) return 4;
             printf("%llu %llu %.17g %s\n", (unsigned long long)lo, (unsigned long long)hi, g, mcp_last_error());
             return 0;

@@ -515,3 +515,29 @@ def test_portfolio_sharded_engine_two_ranks_on_one_gpu(gpu_ctx, tmp_path):
     want = simulate_paths(mu, cov, W, n_steps=20, n_paths=6000, seed=321, rf=0.001, as_array=True)
     for key in want.dtype.names:
         assert np.array_equal(a[key], want[key]), key
+
+
+@pytest.mark.parametrize("N,T,P,comp", [(16, 252, 20_000, "simple"), (3, 40, 5000, "simple"), (37, 12, 2000, "log"), (64, 9, 1000, "simple")])
+def test_folded_fast_path(gpu_ctx, N, T, P, comp):
+    """MCP_FLAG_FOLD (SPEC.md 4.1): rho = w.mu + (L^T w).z, one portfolio.  Bit-identical to the oracle's folded mode;
+    against the unfolded recurrence only the rounding differs (same normals): terminal values within 2e-6 relative,
+    statistics within north_star's 1e-6."""
+    mu, cov = synthetic.synthetic_market(N)
+    w = synthetic.dirichlet_weights(N, 1, seed=N)[0]
+    got = simulate_paths(mu, cov, w, n_steps=T, n_paths=P, seed=SEED, store=True, compounding=comp, fold=True)
+    mu32, L, W32 = prepare_inputs(mu, cov, w)
+    ref_fold = mc_oracle.simulate(mu32, L, W32, T, P, SEED, compounding=comp, fold=True)
+    assert np.array_equal(got["terminal"].view(np.uint32), ref_fold[0].view(np.uint32))
+    ref = mc_oracle.simulate(mu32, L, W32, T, P, SEED, compounding=comp)
+    diff = np.abs(got["terminal"].astype(np.float64) - ref[0])
+    assert np.max(diff / (1.0 if comp == "log" else np.abs(ref[0]))) < (2e-7 if comp == "log" else 2e-6)   # S_T absolute, V_T relative
+    want = ref_stats.path_stats(ref[0], compounding=comp)
+    assert got["n_tail"] == want["n_tail"]
+    for key in ("mean", "std", "sharpe", "var", "cvar"):
+        assert abs(got[key] - want[key]) <= 1e-6 * max(1.0, abs(want[key])), key
+
+
+def test_fold_is_refused_for_several_portfolios(gpu_ctx):
+    mu, cov = synthetic.synthetic_market(4)
+    with pytest.raises(_ffi.McpError, match="MCP_FLAG_FOLD"):
+        simulate_paths(mu, cov, synthetic.dirichlet_weights(4, 2), n_steps=3, n_paths=64, fold=True)
