@@ -206,7 +206,8 @@ class PathEngine:
         self.cur = (i + 1) % self.n_buf
 
     def launch_paths_only(self, seed: int, path_base: int = 0):
-        """The dominant kernel alone, on the current stream (roofline timing)."""
+        """The dominant kernel alone, on the CURRENT stream into the most recent buffer (roofline timing).  Call
+        synchronize() first if batches enqueued by step() may still be in flight."""
         self._enqueue_paths(self.bufs[self.last], seed, path_base)
 
     def synchronize(self):
@@ -242,4 +243,4 @@ class PathEngine:
         else:
             out = mine
         rec = out.cpu().numpy().view(np.uint8).view(_ffi.STATS_DTYPE)
-        return rec[:self.k_all].copy() if self.gather_world * self.k_chunk >= self.k_all else rec.copy()
+        return rec[:self.k_all].copy()          # drop the zero-weight padding rows of the last rank
