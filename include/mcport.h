@@ -147,6 +147,10 @@ int mcp_launch_paths(const mcp_params *prm, const float *d_packed, uint64_t seed
 int mcp_launch_moments(const mcp_params *prm, const float *d_terminal, uint64_t terminal_stride, uint64_t n,
                        void *d_partials, void *d_moments, void *stream);
 
+/* Multi-GPU: merge the all-gathered moment records of `world` ranks, d_gathered [world][K] mcp_moments in rank order
+ * (SUM on n, sum, sumsq; MIN on min; MAX on max) into d_moments [K]. */
+int mcp_launch_moments_merge(int n_portfolios, int world, const void *d_gathered, void *d_moments, void *stream);
+
 /* np.percentile(x, (1-alpha)*100) bookkeeping (numpy 2.2 `_compute_virtual_index`/`_get_indexes`,
  * method 'linear'; the q of app.py:259): ranks of the two order statistics and the weight. */
 int mcp_percentile_rank(uint64_t n_total, double alpha, uint64_t *rank_lo, uint64_t *rank_hi, double *gamma);

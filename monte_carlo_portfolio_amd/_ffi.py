@@ -79,6 +79,7 @@ SIGNATURES = {
     "mcp_pack_params": (_int, [_int, _int, _f32p, _f32p, _f32p, _f32p, ctypes.c_size_t]),
     "mcp_launch_paths": (_int, [_PP, _vp, _u64, _u64, _u64, _vp, _u64, _vp]),
     "mcp_launch_moments": (_int, [_PP, _vp, _u64, _u64, _vp, _vp, _vp]),
+    "mcp_launch_moments_merge": (_int, [_int, _int, _vp, _vp, _vp]),
     "mcp_percentile_rank": (_int, [_u64, ctypes.c_double, ctypes.POINTER(_u64), ctypes.POINTER(_u64),
                                    ctypes.POINTER(ctypes.c_double)]),
     "mcp_launch_select_init": (_int, [_int, _u64, _u64, _vp, _vp]),

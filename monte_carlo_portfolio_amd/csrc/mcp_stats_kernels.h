@@ -43,6 +43,7 @@ hipError_t launch_sweep_paths(int nb, int mt, bool native, const PathArgs& args,
 hipError_t launch_normals(const uint32_t* x, uint64_t n, const float4* table, float* z, hipStream_t s);
 hipError_t launch_moments(const mcp_params& prm, int K, const float* terminal, uint64_t stride, uint64_t n,
                           mcp_moments* partials, mcp_moments* out, hipStream_t s);
+hipError_t launch_moments_merge(int K, int world, const mcp_moments* gathered, mcp_moments* out, hipStream_t s);
 hipError_t launch_select_init(int K, uint64_t rank_lo, uint64_t rank_hi, SelectState* state, hipStream_t s);
 hipError_t launch_select_hist(int K, const float* terminal, uint64_t stride, uint64_t n, int pass,
                               const SelectState* state, unsigned long long* hist, hipStream_t s);

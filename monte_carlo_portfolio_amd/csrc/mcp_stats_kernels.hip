@@ -62,6 +62,23 @@ __global__ void __launch_bounds__(256) moments_kernel(const mcp_moments* __restr
   }
 }
 
+// gathered [world][K] moment records of all ranks -> merged [K] (SUM on n, sum, sumsq; MIN; MAX), rank order fixed
+__global__ void moments_merge_kernel(int K, int world, const mcp_moments* __restrict__ gathered, mcp_moments* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  mcp_moments m = gathered[k];
+  for (int r = 1; r < world; r++) {
+    const mcp_moments g = gathered[(size_t)r * K + k];
+    m.n += g.n; m.sum += g.sum; m.sumsq += g.sumsq; m.min = fmin(m.min, g.min); m.max = fmax(m.max, g.max);
+  }
+  out[k] = m;
+}
+
+hipError_t launch_moments_merge(int K, int world, const mcp_moments* gathered, mcp_moments* out, hipStream_t s) {
+  moments_merge_kernel<<<(K + 63) / 64, 64, 0, s>>>(K, world, gathered, out);
+  return hipGetLastError();
+}
+
 // ---- radix select -------------------------------------------------------------------------------
 // state[k][w] (w = 0: rank lo, w = 1: rank hi): {prefix, rank within the prefix}.
 

@@ -3,7 +3,7 @@
 PyTorch is plumbing only here: it allocates the device buffers, provides the HIP stream the kernels
 are enqueued on, and carries the RCCL collectives (torch.distributed backend "nccl" on ROCm).  Every
 kernel is launched through libmcport.so's C ABI (include/mcport.h, mcp_launch_*) by `HipKernels`;
-nothing on the path is a torch op except the three-line merge of the gathered moments.
+nothing on the path is a torch op.
 
 Sharding: rank g simulates the global path range [g*P, (g+1)*P); the Philox
 counter carries the *global* path id, so any partition yields the same terminal values.  Exchanges
@@ -51,6 +51,9 @@ class HipKernels:
     def moments(self, prm, terminal, n, partials, moments):
         _ffi.check(self.lib.mcp_launch_moments(ctypes.byref(prm), self._p(terminal), terminal.shape[1], n,
                                                self._p(partials), self._p(moments), self._stream()))
+
+    def moments_merge(self, K, world, gathered, moments):
+        _ffi.check(self.lib.mcp_launch_moments_merge(K, world, self._p(gathered), self._p(moments), self._stream()))
 
     def select_init(self, K, lo, hi, state):
         _ffi.check(self.lib.mcp_launch_select_init(K, lo, hi, self._p(state), self._stream()))
@@ -168,10 +171,7 @@ class PathEngine:
         k.moments(self.prm, b["terminal"], n, ws[_ffi.WS_PARTIALS], ws[_ffi.WS_MOMENTS])
         if dist is not None:
             dist.all_gather_into_tensor(b["gather"], b["moments"], group=self.group)
-            g = b["gather"].view(self.world, K, 5)
-            b["moments"][:, 0:3] = g[:, :, 0:3].sum(dim=0)
-            b["moments"][:, 3] = g[:, :, 3].amin(dim=0)
-            b["moments"][:, 4] = g[:, :, 4].amax(dim=0)
+            k.moments_merge(K, self.world, b["gather"], ws[_ffi.WS_MOMENTS])
         k.select_init(K, self.rank_lo, self.rank_hi, ws[_ffi.WS_STATE])
         for p in range(3):
             k.select_hist(K, b["terminal"], n, p, ws[_ffi.WS_STATE], ws[_ffi.WS_HIST])

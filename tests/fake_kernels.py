@@ -50,6 +50,13 @@ class FakeKernels:
             x = ref_stats.terminal_to_x(terminal.numpy()[k, :n], prm.v0, comp)
             m[k] = [x.size, x.sum(), (x * x).sum(), x.min(), x.max()]
 
+    def moments_merge(self, K, world, gathered, moments):
+        g = gathered.numpy().reshape(world, K, 5)
+        m = self._np(moments, np.float64).reshape(K, 5)
+        m[:, 0:3] = g[:, :, 0:3].sum(axis=0)
+        m[:, 3] = g[:, :, 3].min(axis=0)
+        m[:, 4] = g[:, :, 4].max(axis=0)
+
     def select_init(self, K, lo, hi, state):
         s = self._np(state, np.uint64).reshape(K, 2, 2)
         s[:, :, 0] = 0
