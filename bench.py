@@ -2,9 +2,11 @@
 """bench.py -- BASELINE.json's metric on MI355X: simulated paths/s at 16 assets x 252 steps (+ VaR
 abs-err vs the oracle), one process per GPU.
 
-  python bench.py [--gpus N --steps K --warmup W]
+  python bench.py [--gpus N --steps K --warmup W]        N > 1: this process touches no GPU; it starts N rank processes
+                                                         (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their env), relays rank 0's
+                                                         JSON line and exits non-zero if any rank does
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W          the same ranks under an external launcher
 
 A "step" is one full pass of the hot path over one batch resident in HBM: fused path kernel
 (Philox -> inverse-CDF normals -> Cholesky GEMV -> compounding) for BASELINE configs[1] per GPU (16 synthetic
@@ -36,16 +38,72 @@ HBM_BYTES_PER_PATH = 4                                                          
 #   Philox   80 v_mad_u64_u32 x 4.7 + 80 three-input xor x 2.6                            =  584
 #   8 pairs  2 cvt x 4.4 + 4 transcendentals x 8.2 + 5 packed fp ops x 2.15               =  419
 #   GEMV     136 FMA as 68 v_pk_fma_f32 x 4.3; weight dot 8 v_pk_fma_f32; compound 1 x 2.6 =  329
-ISSUE_CYCLES_PER_WAVE_STEP = (80 * 4.7 + 80 * 2.6) + 8 * (2 * 4.4 + 4 * 8.2 + 5 * 2.15) + (68 * 4.3 + 8 * 4.3 + 2.6)
+ISSUE_MODEL = json.load(open(os.path.join(ROOT, "profiles", "issue_model.json")))     # the ceiling's instruction table, as data
+ISSUE_CYCLES_PER_WAVE_STEP = sum(r["count"] * r["cycles"] for r in ISSUE_MODEL["rows"])
 VALU_CEILING_PATHS_PER_S = 1024 * 2.4e9 * 64 / (ISSUE_CYCLES_PER_WAVE_STEP * N_STEPS)
 HBM_PEAK_GBS = 8000.0
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 
 
+def physical_cores():
+    """Physical cores this process may run on (lscpu-style: unique (package, core) pairs of the allowed CPUs)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    seen = set()
+    for c in cpus:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except OSError:
+            seen.add(("?", str(c)))
+    return len(seen), len(cpus)
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` typed as such: the parent makes NO GPU call (it never imports torch); it starts N fresh
+    rank processes, relays rank 0's stdout (the JSON line) and returns non-zero if any rank failed."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MCP_BENCH_RANK_PROCESS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        time.sleep(0.1)
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:                         # a dead rank leaves the others waiting in a collective
+                    procs[q].terminate()                # exact PIDs this function started
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(buf).decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return rc
+
+
 def cpu_baseline(mu32, L, W32, seed):
     """The oracle (CPU port of the same spec) on this box's host cores, bounded to ~10-20 s."""
     from oracle import mc_oracle
-    threads = min(os.cpu_count() or 1, 64)
+    cores, logical = physical_cores()
+    threads = min(logical, 64)
     t0 = time.perf_counter()
     mc_oracle.simulate(mu32, L, W32, N_STEPS, 4096, seed, n_threads=threads)
     rate = 4096 / (time.perf_counter() - t0)
@@ -53,8 +111,61 @@ def cpu_baseline(mu32, L, W32, seed):
     t0 = time.perf_counter()
     term = mc_oracle.simulate(mu32, L, W32, N_STEPS, n, seed, n_threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "paths/s", "cores": threads, "kind": "port",
-            "sample": f"{n} paths of the bench workload (16 assets x 252 steps, seed 0x5EED5EED), oracle/mc_oracle.c, {threads} threads"}, term
+    return {"value": n / dt, "unit": "paths/s", "cores": threads, "physical_cores": cores, "logical_cpus": logical, "kind": "port",
+            "sample": f"{n} paths of the bench workload (16 assets x 252 steps, seed 0x5EED5EED), oracle/mc_oracle.c, "
+                      f"{threads} threads on {cores} physical cores"}, term
+
+
+def mc_oracle_f64(mu32, L, W32, seed, n):
+    from oracle import mc_oracle
+    return mc_oracle.simulate_f64(mu32, L, W32, N_STEPS, n, seed)[0]
+
+
+def numpy_baseline(mu32, L, W32, seed, budget_s=8.0):
+    """the NumPy CPU loop of the same model (oracle/np_oracle.py, float64 = the reference's
+    arithmetic: Z @ L.T, returns @ w, running product), single process, bounded."""
+    from oracle import np_oracle
+    t0 = time.perf_counter()
+    np_oracle.simulate(mu32, L, W32, N_STEPS, 2048, seed, dtype=np.float64)
+    rate = 2048 / (time.perf_counter() - t0)
+    n = int(min(max(rate * budget_s, 4096), 200_000))
+    t0 = time.perf_counter()
+    np_oracle.simulate(mu32, L, W32, N_STEPS, n, seed, dtype=np.float64)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "paths/s", "cores": 1, "kind": "port", "dtype": "f64",
+            "sample": f"{n} paths of the bench workload, oracle/np_oracle.py (pure NumPy, float64, one process; BLAS threads as configured)"}
+
+
+
+def rehearsal(args, world, rank):
+    """CPU rehearsal of the multi-rank bench (launcher + PathEngine choreography over gloo with the NumPy/oracle test
+    double).  Not a measurement: the line says so."""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fake_kernels import FakeKernels
+    from monte_carlo_portfolio_amd import synthetic
+    from monte_carlo_portfolio_amd.engine import PathEngine
+    from monte_carlo_portfolio_amd.simulate import prepare_inputs
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_local = min(PATHS_PER_GPU, 2000)
+    mu, cov = synthetic.synthetic_market(N_ASSETS)
+    mu32, L, W32 = prepare_inputs(mu, cov, synthetic.equal_weights(N_ASSETS))
+    eng = PathEngine(mu32, L, W32, 16, n_local, device="cpu", kernels=FakeKernels(mu32, L, W32),
+                     group=dist.group.WORLD if world > 1 else None, world_size=world, rank=rank)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step(synthetic.BENCH_SEED)
+    st = eng.stats()[0]
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL (gloo + CPU test double, not a measurement)", "value": n_local * world * args.steps / dt,
+                          "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "data": "synthetic",
+                          "stats": {"n": int(st["n"]), "n_tail": int(st["n_tail"]), "var95": float(st["var"])}}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -65,6 +176,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--native-math", action="store_true", help="normals by hardware log/sqrt/sin/cos Box-Muller (not the spec's values)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spawn", action="store_true", help="go through the rank-spawning parent also for --gpus 1")
+    ap.add_argument("--backend", default=os.environ.get("MCP_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo-fake"],
+                    help="gloo-fake: CPU rehearsal of the launcher and the rank choreography (tests/fake_kernels.py over gloo); "
+                         "prints a line marked rehearsal, never a measurement")
     ap.add_argument("--sweep", action="store_true",
                     help="side benchmark, NOT the BASELINE metric: configs[4] shape (10,000 Dirichlet portfolios, 16 assets, "
                          "252 steps, --sweep-paths paths), portfolio-sharded over the ranks, MFMA kernel")
@@ -75,6 +190,10 @@ def main():
 
     PATHS_PER_GPU = args.paths_per_gpu
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        # typed as `python bench.py --gpus N`: start the ranks from here, before anything touches a GPU
+        sys.exit(spawn_ranks(args.gpus, [a for a in sys.argv[1:] if a != "--spawn"]))
+
     import torch
     import torch.distributed as dist
 
@@ -82,8 +201,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("MCP_BENCH_FAIL_RANK") == str(rank):        # test hook: a rank that dies must fail the whole run
+        sys.exit(3)
+    if args.backend == "gloo-fake":
+        return rehearsal(args, world, rank)
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:     # under torch.distributed.run also with one rank (exercises RCCL)
@@ -174,7 +296,7 @@ def main():
         torch.cuda.synchronize()
         nk_ms = ev0.elapsed_time(ev1) / n_k
         native = {"kernel_ms": nk_ms, "kernel_paths_per_s": PATHS_PER_GPU / (nk_ms * 1e-3),
-                  "frac": PATHS_PER_GPU / (nk_ms * 1e-3) / VALU_CEILING_PATHS_PER_S,
+                  "frac_of_issue_model": PATHS_PER_GPU / (nk_ms * 1e-3) / VALU_CEILING_PATHS_PER_S,
                   "note": "MCP_FLAG_NATIVE_MATH: normals by v_log/v_sqrt/v_sin/v_cos Box-Muller (the mix the ceiling is priced on); "
                           "same distribution, other values than the spec"}
 
@@ -198,31 +320,41 @@ def main():
         total_paths = PATHS_PER_GPU * world * args.steps
         value = total_paths / elapsed
         k_paths_s = PATHS_PER_GPU / (k_ms * 1e-3)
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(prof):
-            try:
-                traffic = json.load(open(prof)).get("mc_paths_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_src = None, None
+        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+            prof = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(prof):
+                try:
+                    traffic = json.load(open(prof)).get("mc_paths_kernel_hbm_bytes_per_launch")
+                    traffic_src = f"replayed from profiles/{name} (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of this kernel at this shape; not measured in this run)"
+                except Exception:
+                    traffic = None
+                break
+        achieved_tf = MODEL_FLOPS_PER_PATH * k_paths_s / 1e12
         roofline = {
             "bound": "valu",
             "kernel": "mc_paths_kernel<4,1,1,false>",
-            "achieved": MODEL_FLOPS_PER_PATH * k_paths_s / 1e12,
-            "peak": MODEL_FLOPS_PER_PATH * VALU_CEILING_PATHS_PER_S / 1e12,
+            "achieved": achieved_tf,
+            "peak": FP32_VECTOR_PEAK_TFLOPS,
             "unit": "TFLOP/s",
-            "frac": k_paths_s / VALU_CEILING_PATHS_PER_S,
+            "frac": achieved_tf / FP32_VECTOR_PEAK_TFLOPS,
             "traffic": traffic,
+            "traffic_source": traffic_src,
             "kernel_ms": k_ms,
             "kernel_paths_per_s": k_paths_s,
-            "note": "VALU-issue bound (SURVEY 0.4/8d): achieved/peak = model fp32 FLOPs (77,112/path) x paths/s; "
-                    "peak = issue-cycle ceiling of the cheapest instruction mix for this algorithm at issue costs "
-                    "measured on gfx950 (1,332 cycles per wave-step, DESIGN.md section 4), not the 157.3 TFLOP/s fp32 "
-                    "vector peak; the spec's kernel draws its normals by a table-driven inverse CDF (bit-reproducible, 12 VALU "
-                    "ops per normal) instead of hardware-transcendental Box-Muller",
+            "pipelined_ms_per_step": elapsed / args.steps * 1e3,
+            "frac_of_issue_model": k_paths_s / VALU_CEILING_PATHS_PER_S,
+            "issue_model": {"cycles_per_wave_step": ISSUE_CYCLES_PER_WAVE_STEP, "ceiling_paths_per_s": VALU_CEILING_PATHS_PER_S,
+                            "table": "profiles/issue_model.json"},
+            "note": "VALU-issue bound (SURVEY 0.4/8d): neither HBM (4 B/path) nor MFMA binds.  achieved = model fp32 FLOPs "
+                    "(77,112 per path, SURVEY 8d) x paths/s of ONE serial launch (kernel_ms, HIP events on the launch stream); "
+                    "peak = the 157.3 TFLOP/s fp32 vector peak of MI355X_MICROARCH.md.  The model FLOPs are 9 % of the "
+                    "instructions the algorithm needs (Philox and the normal transform carry no model FLOPs), so frac_of_issue_model "
+                    "prices the same launch against a builder-authored issue-cycle table (profiles/issue_model.json).  "
+                    "pipelined_ms_per_step < kernel_ms because PathEngine alternates two path streams: batch i+1's first "
+                    "waves fill the CUs the partial last round of batch i's 15,625 waves leaves idle (profiles/r02_overlap.txt)",
             "native_math_kernel": native,
             "folded_kernel": fold,
-            "frac_of_fp32_vector_peak": MODEL_FLOPS_PER_PATH * k_paths_s / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
             "hbm": {"achieved": HBM_BYTES_PER_PATH * k_paths_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": HBM_BYTES_PER_PATH * k_paths_s / 1e9 / HBM_PEAK_GBS},
         }
@@ -254,6 +386,16 @@ def main():
             out["var_abs_err"] = abs(g["var"] - want["var"])
             out["sharpe_rel_err"] = abs(g["sharpe"] - want["sharpe"]) / abs(want["sharpe"])
             out["var_check_paths"] = n
+            # the same draws evaluated in float64 (the reference's arithmetic, app.py:258-263/708-713): what the fp32
+            # recurrence costs in accuracy.  north_star's bar: 1e-6.
+            x64 = mc_oracle_f64(mu32, L, W32, seed, n) - 1.0
+            v64 = ref_stats.var(x64)
+            s64 = x64.mean() / x64.std(ddof=1)
+            out["var_abs_err_f64"] = abs(g["var"] - v64)
+            out["sharpe_rel_err_f64"] = abs(g["sharpe"] - s64) / abs(s64)
+            out["cvar_abs_err_f64"] = abs(g["cvar"] - ref_stats.cvar(x64))
+            out["mean_abs_err_f64"] = abs(g["mean"] - x64.mean())
+            out["cpu_baseline_numpy"] = numpy_baseline(mu32, L, W32, seed)
             # side figure: the reference's own loop, app.py:699-717, on historical rows
             from monte_carlo_portfolio_amd import sweep
             Rm = np.random.default_rng(0).normal(0.0005, 0.02, (252, N_ASSETS))

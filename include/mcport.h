@@ -23,16 +23,18 @@
 extern "C" {
 #endif
 
-#define MCP_ABI_VERSION 1
+#define MCP_ABI_VERSION 2
 #define MCP_MAX_ASSETS 64        /* thread-per-path kernels are instantiated for N4 = 4..64 */
 #define MCP_SELECT_BINS 2048     /* radix-select digit: 11 + 11 + 10 bits */
 
 enum {
     MCP_OK = 0,
     MCP_E_ARG = -1,        /* bad argument (shape, NULL, range) */
-    MCP_E_NODEVICE = -2,   /* no HIP device / HIP runtime error; message has the HIP error string */
+    MCP_E_NODEVICE = -2,   /* no HIP device visible (the product has no CPU fallback) */
     MCP_E_NOMEM = -3,
-    MCP_E_UNSUPPORTED = -4
+    MCP_E_UNSUPPORTED = -4,
+    MCP_E_HIP = -5,        /* a HIP runtime call or kernel launch failed; mcp_last_error() has the call and the HIP error string */
+    MCP_E_COMM = -6        /* RCCL could not be loaded or a collective failed (multi-device contexts only) */
 };
 
 enum {
@@ -44,9 +46,11 @@ enum {
     MCP_FLAG_NATIVE_MATH = 1,  /* normals by Box-Muller on the v_log/v_sqrt/v_sin/v_cos hardware approximations instead
                                   of the spec's inverse-CDF table: statistically equivalent draws from the same Philox
                                   stream, NOT comparable to the oracle value by value */
-    MCP_FLAG_FOLD = 2          /* one portfolio only: rho = w.mu + (L^T w).z with L^T w folded on the host (SPEC.md 4.1)
+    MCP_FLAG_FOLD = 2,         /* one portfolio only: rho = w.mu + (L^T w).z with L^T w folded on the host (SPEC.md 4.1)
                                   instead of the triangular GEMV + weight dot.  A separately reported fast path: same
                                   normals, other rounding than the unfolded recurrence (agrees to ~1e-7 relative) */
+    MCP_FLAG_SHARD_PORTFOLIOS = 4  /* multi-device contexts: every device walks ALL paths for its slice of the K weight
+                                  vectors (BASELINE configs[4]; no collective at all) instead of sharding the path range */
 };
 
 typedef struct mcp_ctx mcp_ctx;
@@ -80,11 +84,13 @@ typedef struct {
     double x_lo, x_hi;      /* the two order statistics np.percentile interpolates between */
 } mcp_stats;
 
-/* Raw sufficient statistics of one portfolio on one device: what ranks all-reduce (SUM on the first
- * three, MIN / MAX on the last two). */
+/* Raw sufficient statistics of one portfolio on one device: what ranks exchange (one all-gather, merged in rank
+ * order: SUM on n, sum, sumsq, below; MIN on min; MAX on max).  `below` = sum of x over this device's paths that sort
+ * strictly below the bucket of the low order statistic of the radix select (the CVaR tail, app.py:261-263). */
 typedef struct {
-    double n, sum, sumsq, min, max;
-} mcp_moments;
+    double n, sum, sumsq, min, max, below;
+    double pad[2];
+} mcp_record;
 
 int mcp_abi_version(void);
 int mcp_device_count(void);                 /* 0 when no GPU is visible; never fails */
@@ -93,7 +99,20 @@ const char *mcp_last_error(void);
 /* ---- host-level API: NumPy in, NumPy out (replaces the script lines app.py:699-717 for a simulated
  *      terminal distribution).  Owns its device buffers; calls on one ctx are serialised. ---------- */
 int mcp_ctx_create(int device, mcp_ctx **out);
+/* one context over `ndev` devices, one stream per device, the path range (or, with
+ * MCP_FLAG_SHARD_PORTFOLIOS, the weight matrix) sharded over them.  Distinct devices exchange through RCCL
+ * (ncclCommInitAll; librccl is loaded at run time, MCP_E_COMM if that fails); a device listed more than once holds
+ * several logical shards that exchange through a kernel (what a one-GPU box can exercise).  ndev = 1 is
+ * mcp_ctx_create.  Results equal the one-device results: order statistics, counts and argmax exactly, fp64 sums up to
+ * association. */
+int mcp_ctx_create_multi(const int *devices, int ndev, mcp_ctx **out);
+int mcp_ctx_device_count(const mcp_ctx *ctx);   /* number of shards of the context */
 void mcp_ctx_destroy(mcp_ctx *ctx);
+
+/* Large K: the terminal values are produced and reduced in tiles of portfolios so that at most about
+ * `bytes` of V_T are resident per device (default 8 GiB; SURVEY.md section 8a N2: V_T[K x paths] is never
+ * materialised whole unless terminal_out asks for it). */
+int mcp_ctx_set_terminal_budget(mcp_ctx *ctx, size_t bytes);
 
 int mcp_simulate(mcp_ctx *ctx, const mcp_params *prm,
                  const float *mu,      /* [N] */
@@ -115,19 +134,20 @@ int mcp_sweep_historical(mcp_ctx *ctx, int n_assets, int n_rows, int n_portfolio
 
 /* ---- device-level API: the same kernels as separate enqueue-only steps, for a host that owns the
  *      buffers and the collectives (one process per GPU, torch.distributed over RCCL).  Work buffers
- *      are opaque device memory of the byte sizes given by mcp_ws_bytes().  Between a *_hist step and
- *      its *_scan step (and after mcp_launch_moments / mcp_launch_tail) a multi-GPU host all-reduces
- *      the buffer in place; a single-GPU host just runs the steps back to back. -------------------- */
+ *      are opaque device memory of the byte sizes given by mcp_ws_bytes(); they must be ZERO when first
+ *      used (the steps clear what they consume).  One pass, in this order:
+ *          paths -> pass0 -> [all-reduce HIST] -> scan(0) -> hist(1) -> [all-reduce HIST] -> scan(1)
+ *                -> hist(2) -> [all-reduce HIST] -> final -> [all-gather RECORD -> stats]
+ *      A single-GPU host skips the bracketed exchanges and passes d_stats to mcp_launch_final. -------- */
 
 enum {
-    MCP_WS_PARTIALS = 0,   /* [K][256] mcp_moments: per-block partials of the moments pass          */
-    MCP_WS_MOMENTS = 1,    /* [K] mcp_moments: all-reduce SUM on {n,sum,sumsq}, MIN on min, MAX on max */
-    MCP_WS_STATE = 2,      /* [K][2] select state {u32 prefix, u32 pad, u64 rank}                   */
-    MCP_WS_HIST = 3,       /* [K][2][MCP_SELECT_BINS] uint64: all-reduce SUM                        */
-    MCP_WS_QUANT = 4,      /* [K] {double x_lo, x_hi, var}                                          */
-    MCP_WS_TAIL_PARTIAL = 5,
-    MCP_WS_TAIL = 6,       /* [K] {double count, double sum}: all-reduce SUM                        */
-    MCP_WS_STATS = 7       /* [K] mcp_stats                                                         */
+    MCP_WS_PARTIALS = 0,   /* [K][slots(K)][6] double: per-block partials of the streaming passes      */
+    MCP_WS_RECORD = 1,     /* [K] mcp_record: this device's sufficient statistics (all-gathered)        */
+    MCP_WS_STATE = 2,      /* [K][2] select state {u32 prefix, u32 pad, u64 rank}                       */
+    MCP_WS_HIST = 3,       /* [K][2][MCP_SELECT_BINS] uint64: all-reduce SUM after pass0 / hist         */
+    MCP_WS_QUANT = 4,      /* [K] {double x_lo, x_hi, var, level2; u64 n_tail, pad}: identical on all ranks */
+    MCP_WS_STATS = 5,      /* [K] mcp_stats                                                             */
+    MCP_WS_COUNT = 6
 };
 size_t mcp_ws_bytes(int which, int n_portfolios);
 
@@ -142,37 +162,32 @@ int mcp_pack_params(int n_assets, int n_portfolios, const float *mu, const float
 int mcp_launch_paths(const mcp_params *prm, const float *d_packed, uint64_t seed, uint64_t path_begin,
                      uint64_t n_paths, float *d_terminal, uint64_t terminal_stride, void *stream);
 
-/* {n, sum x, sum x^2, min, max} of this device's n terminal values per portfolio -> d_moments [K]
- * (fixed-order two-stage fp64 reduction: run-to-run deterministic). */
-int mcp_launch_moments(const mcp_params *prm, const float *d_terminal, uint64_t terminal_stride, uint64_t n,
-                       void *d_partials, void *d_moments, void *stream);
-
-/* Multi-GPU: merge the all-gathered moment records of `world` ranks, d_gathered [world][K] mcp_moments in rank order
- * (SUM on n, sum, sumsq; MIN on min; MAX on max) into d_moments [K]. */
-int mcp_launch_moments_merge(int n_portfolios, int world, const void *d_gathered, void *d_moments, void *stream);
-
 /* np.percentile(x, (1-alpha)*100) bookkeeping (numpy 2.2 `_compute_virtual_index`/`_get_indexes`,
  * method 'linear'; the q of app.py:259): ranks of the two order statistics and the weight. */
 int mcp_percentile_rank(uint64_t n_total, double alpha, uint64_t *rank_lo, uint64_t *rank_hi, double *gamma);
 
-/* Exact order statistics by radix select on the order-preserving key of the float bits.
- * pass 0: key[31:21], pass 1: key[20:10], pass 2: key[9:0].  Per pass: hist (zeroes d_hist, then
- * counts this device's keys that match the prefix found so far) -> [all-reduce] -> scan (descends). */
-int mcp_launch_select_init(int n_portfolios, uint64_t rank_lo, uint64_t rank_hi, void *d_state, void *stream);
-int mcp_launch_select_hist(int n_portfolios, const float *d_terminal, uint64_t terminal_stride, uint64_t n,
-                           int pass, const void *d_state, void *d_hist, void *stream);
-int mcp_launch_select_scan(int n_portfolios, int pass, const void *d_hist, void *d_state, void *stream);
-
-/* VaR from the selected order statistics (numpy `_lerp`). */
-int mcp_launch_quantile(const mcp_params *prm, double gamma, const void *d_state, void *d_quant, void *stream);
-
-/* count and sum of x over this device's paths with x <= VaR (compared in double as app.py:263). */
-int mcp_launch_tail(const mcp_params *prm, const float *d_terminal, uint64_t terminal_stride, uint64_t n,
-                    const void *d_quant, void *d_tail_partial, void *d_tail, void *stream);
-
-/* mean, std (ddof=1), Sharpe, VaR, CVaR -> d_stats [K] mcp_stats. */
-int mcp_launch_stats(const mcp_params *prm, const void *d_moments, const void *d_quant, const void *d_tail,
+/* One read of this device's n terminal values per portfolio: {n, sum x, sum x^2, min, max} partials and the
+ * digit-0 histogram (key bits 31..21) of the exact radix select on the order-preserving key of the float bits. */
+int mcp_launch_pass0(const mcp_params *prm, const float *d_terminal, uint64_t terminal_stride, uint64_t n,
+                     void *d_partials, void *d_hist, void *stream);
+/* pass 0: partials -> d_record, (rank_lo, rank_hi) of the GLOBAL n -> d_state, descend into the digit holding each
+ * rank; pass 1: descend again (and fold the partials of hist pass 1 into d_record).  Clears d_hist. */
+int mcp_launch_scan(const mcp_params *prm, int pass, uint64_t n, uint64_t rank_lo, uint64_t rank_hi, const void *d_partials,
+                    void *d_hist, void *d_state, void *d_record, void *stream);
+/* pass 1 (key bits 20..10) / pass 2 (bits 9..0): digit histograms of the keys matching the prefixes in d_state, and the
+ * sum of x below the low bucket (CVaR tail, app.py:261-263) into d_partials. */
+int mcp_launch_hist(const mcp_params *prm, int pass, const float *d_terminal, uint64_t terminal_stride, uint64_t n,
+                    const void *d_state, void *d_partials, void *d_hist, void *stream);
+/* Last descent -> order statistics -> VaR (numpy `_lerp`) -> d_quant; tail count / in-bucket tail sum from the
+ * (global) histogram; local `below` into d_record.  d_stats != NULL (single device): also mean, std (ddof=1), Sharpe,
+ * CVaR -> d_stats [K] mcp_stats.  Clears d_hist. */
+int mcp_launch_final(const mcp_params *prm, uint64_t n, double gamma, uint64_t rank_lo, uint64_t rank_hi,
+                     const void *d_partials, void *d_hist, const void *d_state, void *d_record, void *d_quant,
                      void *d_stats, void *stream);
+/* Multi-GPU: merge the all-gathered records of `world` ranks, d_gathered [world][K] mcp_record in rank order, and
+ * finish -> d_stats [K] mcp_stats. */
+int mcp_launch_stats(const mcp_params *prm, int world, const void *d_gathered, const void *d_quant, void *d_stats,
+                     void *stream);
 
 /* The normal generator on its own: d_z[i] = inverse-CDF normal (SPEC.md section 3) of the 32-bit word d_x[i]. */
 int mcp_launch_normals(const uint32_t *d_x, uint64_t n, float *d_z, void *stream);

@@ -17,13 +17,16 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmcport.so")
 CSRC = os.path.join(_PKG, "csrc")
 
-MCP_ABI_VERSION = 1
+MCP_ABI_VERSION = 2
 MCP_MAX_ASSETS = 64
 MCP_SELECT_BINS = 2048
 MCP_COMPOUND = {"simple": 0, "log": 1}
 MCP_FLAG_NATIVE_MATH = 1
 MCP_FLAG_FOLD = 2
-(WS_PARTIALS, WS_MOMENTS, WS_STATE, WS_HIST, WS_QUANT, WS_TAIL_PARTIAL, WS_TAIL, WS_STATS) = range(8)
+MCP_FLAG_SHARD_PORTFOLIOS = 4
+MCP_E_ARG, MCP_E_NODEVICE, MCP_E_NOMEM, MCP_E_UNSUPPORTED, MCP_E_HIP, MCP_E_COMM = -1, -2, -3, -4, -5, -6
+(WS_PARTIALS, WS_RECORD, WS_STATE, WS_HIST, WS_QUANT, WS_STATS) = range(6)
+WS_COUNT = 6
 
 
 class McpError(RuntimeError):
@@ -54,8 +57,11 @@ STATS_DTYPE = np.dtype([
 ])
 assert STATS_DTYPE.itemsize == ctypes.sizeof(McpStats)
 
-MOMENTS_DTYPE = np.dtype([("n", np.float64), ("sum", np.float64), ("sumsq", np.float64),
-                          ("min", np.float64), ("max", np.float64)])
+RECORD_DTYPE = np.dtype([("n", np.float64), ("sum", np.float64), ("sumsq", np.float64), ("min", np.float64),
+                         ("max", np.float64), ("below", np.float64), ("pad", np.float64, (2,))])
+QUANT_DTYPE = np.dtype([("x_lo", np.float64), ("x_hi", np.float64), ("var", np.float64), ("level2", np.float64),
+                        ("n_tail", np.uint64), ("pad", np.uint64)])
+RECORD_DOUBLES = RECORD_DTYPE.itemsize // 8
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
@@ -70,6 +76,9 @@ SIGNATURES = {
     "mcp_device_count": (_int, []),
     "mcp_last_error": (ctypes.c_char_p, []),
     "mcp_ctx_create": (_int, [_int, ctypes.POINTER(_vp)]),
+    "mcp_ctx_create_multi": (_int, [ctypes.POINTER(_int), _int, ctypes.POINTER(_vp)]),
+    "mcp_ctx_device_count": (_int, [_vp]),
+    "mcp_ctx_set_terminal_budget": (_int, [_vp, ctypes.c_size_t]),
     "mcp_ctx_destroy": (None, [_vp]),
     "mcp_simulate": (_int, [_vp, _PP, _f32p, _f32p, _f32p, _u64, _u64, _u64, _vp, _vp]),
     "mcp_sweep_historical": (_int, [_vp, _int, _int, _int, _f64p, _f64p, _f64p, _f64p, ctypes.c_double, ctypes.c_double,
@@ -78,16 +87,13 @@ SIGNATURES = {
     "mcp_packed_len": (ctypes.c_size_t, [_int, _int]),
     "mcp_pack_params": (_int, [_int, _int, _f32p, _f32p, _f32p, _f32p, ctypes.c_size_t]),
     "mcp_launch_paths": (_int, [_PP, _vp, _u64, _u64, _u64, _vp, _u64, _vp]),
-    "mcp_launch_moments": (_int, [_PP, _vp, _u64, _u64, _vp, _vp, _vp]),
-    "mcp_launch_moments_merge": (_int, [_int, _int, _vp, _vp, _vp]),
     "mcp_percentile_rank": (_int, [_u64, ctypes.c_double, ctypes.POINTER(_u64), ctypes.POINTER(_u64),
                                    ctypes.POINTER(ctypes.c_double)]),
-    "mcp_launch_select_init": (_int, [_int, _u64, _u64, _vp, _vp]),
-    "mcp_launch_select_hist": (_int, [_int, _vp, _u64, _u64, _int, _vp, _vp, _vp]),
-    "mcp_launch_select_scan": (_int, [_int, _int, _vp, _vp, _vp]),
-    "mcp_launch_quantile": (_int, [_PP, ctypes.c_double, _vp, _vp, _vp]),
-    "mcp_launch_tail": (_int, [_PP, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
-    "mcp_launch_stats": (_int, [_PP, _vp, _vp, _vp, _vp, _vp]),
+    "mcp_launch_pass0": (_int, [_PP, _vp, _u64, _u64, _vp, _vp, _vp]),
+    "mcp_launch_scan": (_int, [_PP, _int, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "mcp_launch_hist": (_int, [_PP, _int, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "mcp_launch_final": (_int, [_PP, _u64, ctypes.c_double, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mcp_launch_stats": (_int, [_PP, _int, _vp, _vp, _vp, _vp]),
     "mcp_launch_normals": (_int, [_vp, _u64, _vp, _vp]),
     "mcp_icdf_table": (_int, [_f32p, ctypes.c_size_t]),
     "mcp_float_to_key": (ctypes.c_uint32, [ctypes.c_float]),
@@ -124,6 +130,25 @@ def _preload_hip_runtime() -> None:
             ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
 
 
+def preload_rccl() -> None:
+    """Multi-device contexts load librccl at run time (dlopen("librccl.so.1") inside libmcport.so).  When torch is
+    installed its bundled librccl (built against the HIP runtime this process already uses) is loaded first, so the
+    library's dlopen resolves to it by SONAME."""
+    if os.environ.get("MCP_RCCL_LIB"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+        if os.path.exists(cand):
+            try:
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib() -> ctypes.CDLL:
     global _LIB
     if _LIB is None:
@@ -151,11 +176,12 @@ def check(rc: int) -> int:
 
 
 def make_params(n_assets, n_steps, n_portfolios, compounding="simple", v0=1.0, alpha=0.95, rf=0.0,
-                native_math=False, fold=False) -> McpParams:
+                native_math=False, fold=False, shard_portfolios=False) -> McpParams:
     if compounding not in MCP_COMPOUND:
         raise ValueError(f"compounding must be 'simple' or 'log', got {compounding!r}")
     return McpParams(int(n_assets), int(n_steps), int(n_portfolios), MCP_COMPOUND[compounding],
-                     (MCP_FLAG_NATIVE_MATH if native_math else 0) | (MCP_FLAG_FOLD if fold else 0), 0,
+                     (MCP_FLAG_NATIVE_MATH if native_math else 0) | (MCP_FLAG_FOLD if fold else 0)
+                     | (MCP_FLAG_SHARD_PORTFOLIOS if shard_portfolios else 0), 0,
                      float(v0), float(alpha), float(rf))
 
 

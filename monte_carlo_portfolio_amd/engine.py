@@ -8,9 +8,9 @@ nothing on the path is a torch op.
 Sharding: rank g simulates the global path range [g*P, (g+1)*P); the Philox
 counter carries the *global* path id, so any partition yields the same terminal values.  Exchanges
 per step:
-  - moments: one all_gather of [K] {n, sum, sumsq, min, max} (40 B per portfolio)
   - VaR: 3 all_reduce(SUM) of the [K][2][2048] uint64 digit histograms of the radix select
-  - CVaR: one all_reduce(SUM) of [K] {count, sum}
+  - moments + CVaR tail: one all_gather of the [K] mcp_record {n, sum, sumsq, min, max, below} (64 B per portfolio),
+    merged in rank order by the statistics kernel
 All are latency-bound; xGMI bandwidth is irrelevant at these sizes.
 
 The kernel launches sit behind the small `HipKernels` interface so that the collective choreography
@@ -48,40 +48,33 @@ class HipKernels:
         _ffi.check(self.lib.mcp_launch_paths(ctypes.byref(prm), self._p(packed), seed, path_begin, n,
                                              self._p(terminal), terminal.shape[1], self._stream()))
 
-    def moments(self, prm, terminal, n, partials, moments):
-        _ffi.check(self.lib.mcp_launch_moments(ctypes.byref(prm), self._p(terminal), terminal.shape[1], n,
-                                               self._p(partials), self._p(moments), self._stream()))
+    def pass0(self, prm, terminal, n, partials, hist):
+        _ffi.check(self.lib.mcp_launch_pass0(ctypes.byref(prm), self._p(terminal), terminal.shape[1], n,
+                                             self._p(partials), self._p(hist), self._stream()))
 
-    def moments_merge(self, K, world, gathered, moments):
-        _ffi.check(self.lib.mcp_launch_moments_merge(K, world, self._p(gathered), self._p(moments), self._stream()))
+    def scan(self, prm, p, n, lo, hi, partials, hist, state, record):
+        _ffi.check(self.lib.mcp_launch_scan(ctypes.byref(prm), p, n, lo, hi, self._p(partials), self._p(hist),
+                                            self._p(state), self._p(record), self._stream()))
 
-    def select_init(self, K, lo, hi, state):
-        _ffi.check(self.lib.mcp_launch_select_init(K, lo, hi, self._p(state), self._stream()))
+    def hist(self, prm, p, terminal, n, state, partials, hist):
+        _ffi.check(self.lib.mcp_launch_hist(ctypes.byref(prm), p, self._p(terminal), terminal.shape[1], n, self._p(state),
+                                            self._p(partials), self._p(hist), self._stream()))
 
-    def select_hist(self, K, terminal, n, p, state, hist):
-        _ffi.check(self.lib.mcp_launch_select_hist(K, self._p(terminal), terminal.shape[1], n, p, self._p(state),
-                                                   self._p(hist), self._stream()))
+    def final(self, prm, n, gamma, lo, hi, partials, hist, state, record, quant, stats):
+        _ffi.check(self.lib.mcp_launch_final(ctypes.byref(prm), n, gamma, lo, hi, self._p(partials), self._p(hist),
+                                             self._p(state), self._p(record), self._p(quant),
+                                             self._p(stats) if stats is not None else None, self._stream()))
 
-    def select_scan(self, K, p, hist, state):
-        _ffi.check(self.lib.mcp_launch_select_scan(K, p, self._p(hist), self._p(state), self._stream()))
-
-    def quantile(self, prm, gamma, state, quant):
-        _ffi.check(self.lib.mcp_launch_quantile(ctypes.byref(prm), gamma, self._p(state), self._p(quant), self._stream()))
-
-    def tail(self, prm, terminal, n, quant, tail_partial, tail):
-        _ffi.check(self.lib.mcp_launch_tail(ctypes.byref(prm), self._p(terminal), terminal.shape[1], n, self._p(quant),
-                                            self._p(tail_partial), self._p(tail), self._stream()))
-
-    def stats(self, prm, moments, quant, tail, stats):
-        _ffi.check(self.lib.mcp_launch_stats(ctypes.byref(prm), self._p(moments), self._p(quant), self._p(tail),
-                                             self._p(stats), self._stream()))
+    def stats(self, prm, world, gathered, quant, stats):
+        _ffi.check(self.lib.mcp_launch_stats(ctypes.byref(prm), world, self._p(gathered), self._p(quant), self._p(stats),
+                                             self._stream()))
 
 
 class PathEngine:
     """One rank's pipeline.  `step()` enqueues one full pass; with `pipeline=True` (default on a GPU) passes
     are double-buffered over two HIP streams: the statistics passes and the collectives of batch i run on
     the statistics stream while the path kernel of batch i+1 already runs on the path stream, so the
-    latency-bound tail of a pass (16 small launches, 5 collectives) is hidden behind VALU-bound work."""
+    latency-bound tail of a pass (6 small launches, 4 collectives) is hidden behind VALU-bound work."""
 
     def __init__(self, mu32, chol32, W32, n_steps, n_paths_local, *, compounding="simple", v0=1.0, alpha=0.95,
                  rf=0.0, native_math=False, device=None, group=None, world_size=1, rank=0, kernels=None,
@@ -126,15 +119,14 @@ class PathEngine:
         self.bufs = []
         for _ in range(self.n_buf):
             b = {"terminal": torch.empty((K, self.n_local), dtype=torch.float32, device=self.device), "ws": {}}
-            for which in range(8):
+            for which in range(_ffi.WS_COUNT):            # zero-initialised: the steps clear what they consume
                 nbytes = lib.mcp_ws_bytes(which, K)
                 b["ws"][which] = torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=self.device)
             # typed views for the collectives
-            b["moments"] = b["ws"][_ffi.WS_MOMENTS].view(torch.float64).view(K, 5)
+            b["record"] = b["ws"][_ffi.WS_RECORD].view(torch.float64).view(K, _ffi.RECORD_DOUBLES)
             b["hist"] = b["ws"][_ffi.WS_HIST]                                  # int64 counts [K][2][2048]
-            b["tail"] = b["ws"][_ffi.WS_TAIL].view(torch.float64).view(K, 2)
             if self.group is not None:
-                b["gather"] = torch.empty((self.world * K, 5), dtype=torch.float64, device=self.device)
+                b["gather"] = torch.empty((self.world * K, _ffi.RECORD_DOUBLES), dtype=torch.float64, device=self.device)
             self.bufs.append(b)
         self.cur = 0                                   # buffer the NEXT step writes
         self.last = 0                                  # buffer of the most recent step
@@ -166,23 +158,22 @@ class PathEngine:
         self.k.paths(self.prm, self.d_packed, seed, path_base + self.rank * n, n, b["terminal"])
 
     def _enqueue_stats(self, b):
-        k, K, n, ws = self.k, self.K, self.n_local, b["ws"]
+        k, n, ws, prm = self.k, self.n_local, b["ws"], self.prm
         dist = self.torch.distributed if self.group is not None else None      # also exercised with 1 rank
-        k.moments(self.prm, b["terminal"], n, ws[_ffi.WS_PARTIALS], ws[_ffi.WS_MOMENTS])
-        if dist is not None:
-            dist.all_gather_into_tensor(b["gather"], b["moments"], group=self.group)
-            k.moments_merge(K, self.world, b["gather"], ws[_ffi.WS_MOMENTS])
-        k.select_init(K, self.rank_lo, self.rank_hi, ws[_ffi.WS_STATE])
+        lo, hi = self.rank_lo, self.rank_hi
+        k.pass0(prm, b["terminal"], n, ws[_ffi.WS_PARTIALS], ws[_ffi.WS_HIST])
         for p in range(3):
-            k.select_hist(K, b["terminal"], n, p, ws[_ffi.WS_STATE], ws[_ffi.WS_HIST])
             if dist is not None:
                 dist.all_reduce(b["hist"], group=self.group)
-            k.select_scan(K, p, ws[_ffi.WS_HIST], ws[_ffi.WS_STATE])
-        k.quantile(self.prm, self.gamma, ws[_ffi.WS_STATE], ws[_ffi.WS_QUANT])
-        k.tail(self.prm, b["terminal"], n, ws[_ffi.WS_QUANT], ws[_ffi.WS_TAIL_PARTIAL], ws[_ffi.WS_TAIL])
+            if p < 2:
+                k.scan(prm, p, n, lo, hi, ws[_ffi.WS_PARTIALS], ws[_ffi.WS_HIST], ws[_ffi.WS_STATE], ws[_ffi.WS_RECORD])
+                k.hist(prm, p + 1, b["terminal"], n, ws[_ffi.WS_STATE], ws[_ffi.WS_PARTIALS], ws[_ffi.WS_HIST])
+            else:
+                k.final(prm, n, self.gamma, lo, hi, ws[_ffi.WS_PARTIALS], ws[_ffi.WS_HIST], ws[_ffi.WS_STATE], ws[_ffi.WS_RECORD],
+                        ws[_ffi.WS_QUANT], None if dist is not None else ws[_ffi.WS_STATS])
         if dist is not None:
-            dist.all_reduce(b["tail"], group=self.group)
-        k.stats(self.prm, ws[_ffi.WS_MOMENTS], ws[_ffi.WS_QUANT], ws[_ffi.WS_TAIL], ws[_ffi.WS_STATS])
+            dist.all_gather_into_tensor(b["gather"], b["record"], group=self.group)
+            k.stats(prm, self.world, b["gather"], ws[_ffi.WS_QUANT], ws[_ffi.WS_STATS])
 
     def step(self, seed: int, path_base: int = 0):
         """Enqueue one full pass (paths -> statistics).  No host sync."""

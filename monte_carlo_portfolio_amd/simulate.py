@@ -16,16 +16,30 @@ import numpy as np
 from . import _ffi
 
 _CTX_LOCK = threading.Lock()
-_CTX: dict[int, "Context"] = {}
+_CTX: dict[tuple, "Context"] = {}
 
 
 class Context:
-    """Owns one mcp_ctx (device buffers + stream) on one GPU.  Calls are serialised by the library."""
+    """Owns one mcp_ctx: device buffers + one stream per device.  `device` is a device index or a sequence of them
+    (one context over several GPUs, exchanging through RCCL inside the library; a device listed
+    more than once holds several logical shards).  Calls are serialised by the library."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device=0, terminal_budget: int | None = None):
+        devs = [int(device)] if np.isscalar(device) else [int(d) for d in device]
         self._h = ctypes.c_void_p()
-        _ffi.check(_ffi.lib().mcp_ctx_create(device, ctypes.byref(self._h)))
-        self.device = device
+        if len(devs) > 1 and len(set(devs)) == len(devs):
+            _ffi.preload_rccl()
+        arr = (ctypes.c_int * len(devs))(*devs)
+        _ffi.check(_ffi.lib().mcp_ctx_create_multi(arr, len(devs), ctypes.byref(self._h)))
+        self.device = devs[0]
+        self.devices = tuple(devs)
+        if terminal_budget is not None:
+            self.set_terminal_budget(terminal_budget)
+
+    def set_terminal_budget(self, nbytes: int):
+        """Upper bound on resident terminal values per device; larger sweeps are produced and reduced in tiles of
+        portfolios (include/mcport.h, mcp_ctx_set_terminal_budget)."""
+        _ffi.check(_ffi.lib().mcp_ctx_set_terminal_budget(self._h, int(nbytes)))
 
     def close(self):
         if self._h:
@@ -49,11 +63,13 @@ class Context:
         return stats, term
 
 
-def default_context(device: int = 0) -> Context:
+def default_context(device=0) -> Context:
+    """Process-wide context per device (or per tuple of devices)."""
+    key = (int(device),) if np.isscalar(device) else tuple(int(d) for d in device)
     with _CTX_LOCK:
-        if device not in _CTX:
-            _CTX[device] = Context(device)
-        return _CTX[device]
+        if key not in _CTX:
+            _CTX[key] = Context(key)
+        return _CTX[key]
 
 
 def cholesky_factor(cov: np.ndarray) -> np.ndarray:
@@ -89,22 +105,28 @@ def stats_to_dict(rec) -> dict:
 
 def simulate_paths(mu, cov, weights, n_steps=252, n_paths=10_000, seed=0, v0=1.0, compounding="simple",
                    rf=0.0, alpha=0.95, devices=None, store=False, path_begin=0, chol=None,
-                   native_math=False, as_array=False, fold=False):
+                   native_math=False, as_array=False, fold=False, shard="auto", context=None):
     """Simulate `n_paths` correlated return paths and reduce them to risk statistics.
 
     mu [N], cov [N,N] are per-step mean and covariance (the reference's `mean_returns`, `cov_matrix`
     of app.py:679-680 divided by `annual_factor`); weights [N] or [K,N].  Returns a dict for a single
     weight vector or a list of dicts for K portfolios (as_array=True: the [K] record array of mcp_stats
     instead); with store=True the dict carries 'terminal' (float32 [n_paths] or [K, n_paths]).
+
+    devices: None / [d] -> one GPU; [d0, d1, ...] -> the path range sharded over those GPUs inside the library (RCCL
+    all-reduce of the radix-select histograms, one all-gather of the moment records).
+    shard="portfolios" (or "auto" with K >= 512 per device) shards the weight matrix instead: every GPU walks all
+    paths for its slice of the portfolios, no collective at all (BASELINE configs[4]).
     """
     single = np.asarray(weights).ndim == 1
     mu32, L, W = prepare_inputs(mu, cov, weights, chol)
-    prm = _ffi.make_params(mu32.shape[0], n_steps, W.shape[0], compounding, v0, alpha, rf, native_math, fold)
-    if devices is not None and len(devices) > 1:
-        raise NotImplementedError("simulate_paths drives ONE GPU per call; for several GPUs run one process per GPU with "
-                                  "engine.PathEngine (torch.distributed / RCCL), see INTEGRATION.md section 4")
-    dev = 0 if not devices else int(devices[0])
-    stats, term = default_context(dev).simulate(prm, mu32, L, W, int(seed), int(path_begin), int(n_paths), store)
+    devs = (0,) if not devices else tuple(int(d) for d in devices)
+    if shard not in ("auto", "paths", "portfolios"):
+        raise ValueError("shard must be 'auto', 'paths' or 'portfolios'")
+    by_portfolio = len(devs) > 1 and (shard == "portfolios" or (shard == "auto" and W.shape[0] >= 512 * len(devs)))
+    prm = _ffi.make_params(mu32.shape[0], n_steps, W.shape[0], compounding, v0, alpha, rf, native_math, fold, by_portfolio)
+    ctx = context if context is not None else default_context(devs)
+    stats, term = ctx.simulate(prm, mu32, L, W, int(seed), int(path_begin), int(n_paths), store)
     if as_array:                      # [K] structured array (fields of mcp_stats), for large sweeps
         return (stats, term) if store else stats
     out = [stats_to_dict(stats[k]) for k in range(W.shape[0])]

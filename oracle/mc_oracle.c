@@ -213,3 +213,73 @@ int mco_simulate(int n_assets, int n_steps, int n_portfolios, int compounding, f
     free(jobs); free(th);
     return 0;
 }
+
+/* ---- float64 evaluation of the same spec ------------------------------------------------------------------
+ * The reference's own arithmetic is binary64 throughout (NumPy/pandas defaults: app.py:258-263, 708-713).  This
+ * mode answers "how far do T fp32 steps drift from what float64 NumPy would compute on IDENTICAL normals":
+ * the Philox words and the fp32 inverse-CDF normals are exactly those of SPEC.md sections 2-3 (promoted to
+ * double), the inputs mu / L / W are the same binary32 values (promoted), and the recurrence of SPEC.md
+ * section 4 -- r = mu + L z, rho = w.r, V <- V(1+rho) -- runs in binary64 in the same order with fma().
+ * Terminal values are doubles; they are NOT what the kernel is compared with bit for bit, they bound its
+ * rounding error (tests/test_f64_drift.py, bench.py var_abs_err_f64). */
+typedef struct {
+    mco_job j;
+    double *terminal64;
+} mco_job64;
+
+static void simulate_range_f64(const mco_job64 *jj)
+{
+    const mco_job *j = &jj->j;
+    const int N = j->n_assets, K = j->n_portfolios, T = j->n_steps;
+    const int nb = (N + 3) / 4, N4 = 4 * nb;
+    const uint32_t k0 = (uint32_t)j->seed, k1 = (uint32_t)(j->seed >> 32);
+    const int logc = (j->compounding & 1) != 0;
+    float z[MCO_MAX_ASSETS];
+    double r[MCO_MAX_ASSETS];
+    double *V = (double *)malloc((size_t)K * sizeof(double));
+    for (uint64_t p = j->p_lo; p < j->p_hi; p++) {
+        const uint64_t path = j->path_begin + p;
+        for (int k = 0; k < K; k++) V[k] = logc ? 0.0 : (double)j->v0;
+        for (int t = 0; t < T; t++) {
+            step_normals(k0, k1, path, (uint32_t)t, nb, z);
+            for (int i = 0; i < N; i++) {
+                double acc = (double)(j->mu[i] + 0.0f);
+                for (int c = 0; c <= i; c++) acc = fma((double)j->chol[i * N + c], (double)z[c], acc);
+                r[i] = acc;
+            }
+            for (int k = 0; k < K; k++) {
+                double rho = 0.0;
+                for (int i = 0; i < N; i++) rho = fma((double)j->W[k * N + i], r[i], rho);
+                if (logc) V[k] = V[k] + rho;
+                else V[k] = fma(V[k], rho, V[k]);
+            }
+        }
+        for (int k = 0; k < K; k++) jj->terminal64[(size_t)k * j->n_paths + p] = V[k];
+    }
+    (void)N4;
+    free(V);
+}
+
+static void *worker64(void *arg) { simulate_range_f64((const mco_job64 *)arg); return NULL; }
+
+int mco_simulate_f64(int n_assets, int n_steps, int n_portfolios, int compounding, float v0,
+                     const float *mu, const float *chol, const float *W, uint64_t seed, uint64_t path_begin,
+                     uint64_t n_paths, double *terminal /* [K*n_paths] */, int n_threads)
+{
+    if (n_assets < 1 || n_assets > MCO_MAX_ASSETS || n_steps < 0 || n_portfolios < 1 || (compounding & ~1)) return -1;
+    if (n_threads < 1) n_threads = 1;
+    if ((uint64_t)n_threads > n_paths) n_threads = n_paths ? (int)n_paths : 1;
+    mco_job64 *jobs = (mco_job64 *)malloc(sizeof(mco_job64) * n_threads);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * n_threads);
+    for (int i = 0; i < n_threads; i++) {
+        mco_job jb = {n_assets, n_steps, n_portfolios, compounding, v0, mu, chol, W, seed, path_begin,
+                      n_paths, n_paths * i / n_threads, n_paths * (i + 1) / n_threads, NULL};
+        jobs[i].j = jb;
+        jobs[i].terminal64 = terminal;
+    }
+    for (int i = 1; i < n_threads; i++) pthread_create(&th[i], NULL, worker64, &jobs[i]);
+    simulate_range_f64(&jobs[0]);
+    for (int i = 1; i < n_threads; i++) pthread_join(th[i], NULL);
+    free(jobs); free(th);
+    return 0;
+}

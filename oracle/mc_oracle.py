@@ -41,6 +41,9 @@ def lib() -> ctypes.CDLL:
                                    _f32p, _f32p, _f32p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                    _f32p, ctypes.c_int]
         L.mco_simulate.restype = ctypes.c_int
+        L.mco_simulate_f64.argtypes = L.mco_simulate.argtypes[:11] + [np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS"),
+                                                                      ctypes.c_int]
+        L.mco_simulate_f64.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -90,4 +93,23 @@ def simulate(mu, chol, W, n_steps: int, n_paths: int, seed: int, path_begin: int
                             seed, path_begin, n_paths, out, n_threads)
     if rc != 0:
         raise ValueError(f"mco_simulate failed rc={rc}")
+    return out
+
+
+def simulate_f64(mu, chol, W, n_steps: int, n_paths: int, seed: int, path_begin: int = 0, v0: float = 1.0,
+                 compounding: str = "simple", n_threads: int | None = None) -> np.ndarray:
+    """Terminal values [K, n_paths] float64: the same Philox words, the same fp32 normals and the same binary32
+    inputs as simulate(), recurrence in binary64 (mc_oracle.c, mco_simulate_f64).  Bounds the kernel's rounding."""
+    mu = np.ascontiguousarray(mu, np.float32)
+    chol = np.ascontiguousarray(chol, np.float32)
+    W = np.ascontiguousarray(np.atleast_2d(W), np.float32)
+    n = mu.shape[0]
+    assert chol.shape == (n, n) and W.shape[1] == n
+    out = np.empty((W.shape[0], n_paths), np.float64)
+    if n_threads is None:
+        n_threads = min(os.cpu_count() or 1, 64)
+    rc = lib().mco_simulate_f64(n, n_steps, W.shape[0], {"simple": 0, "log": 1}[compounding], v0, mu, chol, W,
+                                seed, path_begin, n_paths, out, n_threads)
+    if rc != 0:
+        raise ValueError(f"mco_simulate_f64 failed rc={rc}")
     return out

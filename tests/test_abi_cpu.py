@@ -33,12 +33,14 @@ def test_library_exports_every_declared_symbol(mcp_lib):
 def test_struct_layouts(mcp_lib):
     assert ctypes.sizeof(_ffi.McpParams) == 48
     assert ctypes.sizeof(_ffi.McpStats) == 104 == _ffi.STATS_DTYPE.itemsize
-    assert _ffi.MOMENTS_DTYPE.itemsize == 40
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_MOMENTS, 3) == 3 * 40
+    assert _ffi.RECORD_DTYPE.itemsize == 64 and _ffi.QUANT_DTYPE.itemsize == 48
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_RECORD, 3) == 3 * 64
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_QUANT, 3) == 3 * 48
     assert mcp_lib.mcp_ws_bytes(_ffi.WS_STATS, 3) == 3 * 104
     assert mcp_lib.mcp_ws_bytes(_ffi.WS_HIST, 2) == 2 * 2 * 2048 * 8
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_PARTIALS, 2) == 2 * 256 * 40
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_PARTIALS, 2) == 2 * 2048 * 6 * 8 and mcp_lib.mcp_ws_bytes(_ffi.WS_PARTIALS, 10_000) == 10_000 * 8 * 6 * 8
     assert mcp_lib.mcp_ws_bytes(_ffi.WS_STATE, 5) == 5 * 2 * 16
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_COUNT, 5) == 0 and mcp_lib.mcp_ws_bytes(0, 0) == 0
 
 
 def test_pack_params_layout(mcp_lib):
@@ -50,7 +52,10 @@ def test_pack_params_layout(mcp_lib):
     W = rng.normal(size=(K, N)).astype(np.float32)
     p = _ffi.pack_params(mu, L, W)
     n4 = 8
-    assert p.size == n4 + n4 * (n4 // 2 + 1) + 512 * n4 + 4 + n4 == mcp_lib.mcp_packed_len(N, K)
+    kpad = 8                                          # K < 17: whole 8-portfolio passes; K >= 17: whole 512-portfolio workgroups
+    assert p.size == n4 + n4 * (n4 // 2 + 1) + kpad * n4 + 4 + n4 == mcp_lib.mcp_packed_len(N, K)
+    assert mcp_lib.mcp_packed_len(N, 17) == n4 + n4 * (n4 // 2 + 1) + 512 * n4 + 4 + n4
+    assert mcp_lib.mcp_packed_len(N, 513) == n4 + n4 * (n4 // 2 + 1) + 1024 * n4 + 4 + n4
     assert np.array_equal(p[:N], mu) and not np.signbit(p[2]) and np.all(p[N:n4] == 0)
     Lp = p[n4:n4 + n4 * (n4 // 2 + 1)]
     for m in range(n4 // 2):                      # row pairs (2m, 2m+1), columns interleaved
@@ -59,8 +64,8 @@ def test_pack_params_layout(mcp_lib):
                 i = 2 * m + h
                 want = L[i, j] if (i < N and j <= i) else 0.0
                 assert Lp[2 * m * (m + 1) + 2 * j + h] == want
-    Wp = p[n4 + n4 * (n4 // 2 + 1):n4 + n4 * (n4 // 2 + 1) + 512 * n4].reshape(512, n4)
-    F = p[n4 + n4 * (n4 // 2 + 1) + 512 * n4:]            # fold block of portfolio 0: [c, v_0..v_{n4-1}, pad]
+    Wp = p[n4 + n4 * (n4 // 2 + 1):n4 + n4 * (n4 // 2 + 1) + kpad * n4].reshape(kpad, n4)
+    F = p[n4 + n4 * (n4 // 2 + 1) + kpad * n4:]            # fold block of portfolio 0: [c, v_0..v_{n4-1}, pad]
     Lt = np.tril(L).astype(np.float64)
     assert F[0] == np.float32(np.dot(W[0].astype(np.float64), (mu + np.float32(0)).astype(np.float64)))
     np.testing.assert_allclose(F[1:1 + N], (Lt.T @ W[0].astype(np.float64)).astype(np.float32), rtol=2e-7)
@@ -129,7 +134,9 @@ def test_argument_errors_are_reported_not_thrown(mcp_lib):
     assert mcp_lib.mcp_launch_paths(ctypes.byref(prm), None, 0, 0, 100, None, 100, None) == -1
     assert b"NULL device pointer" in mcp_lib.mcp_last_error()
     prm.alpha = 1.5
-    assert mcp_lib.mcp_launch_quantile(ctypes.byref(prm), 0.5, None, None, None) == -1 and b"alpha" in mcp_lib.mcp_last_error()
+    assert mcp_lib.mcp_launch_stats(ctypes.byref(prm), 1, None, None, None, None) == -1 and b"alpha" in mcp_lib.mcp_last_error()
+    prm.alpha = 0.95
+    assert mcp_lib.mcp_launch_scan(ctypes.byref(prm), 2, 10, 0, 1, None, None, None, None, None) == -1     # pass 2 is mcp_launch_final
     with pytest.raises(ValueError):
         _ffi.make_params(4, 10, 1, compounding="weird")
 
@@ -165,7 +172,7 @@ def test_header_is_valid_c99_and_links_from_c(tmp_path, mcp_lib):
             uint64_t lo, hi; double g;
             if (mcp_abi_version() != MCP_ABI_VERSION) return 1;
             if (mcp_percentile_rank(1000000, p.alpha, &lo, &hi, &g) != MCP_OK) return 2;
-            if (mcp_packed_len(16, 1) != 16 + 16 * 9 + 512 * 16 + 20) return 3;
+            if (mcp_packed_len(16, 1) != 16 + 16 * 9 + 8 * 16 + 20) return 3;
             if (mcp_launch_paths(&p, NULL, 0, 0, 10, NULL, 10, NULL) != MCP_E_ARG) return 4;
             printf("%llu %llu %.17g %s\n", (unsigned long long)lo, (unsigned long long)hi, g, mcp_last_error());
             return 0;
@@ -184,7 +191,24 @@ def test_header_is_valid_c99_and_links_from_c(tmp_path, mcp_lib):
     assert "NULL device pointer" in out.stdout
 
 
-def test_multi_device_request_is_refused_not_ignored():
-    from monte_carlo_portfolio_amd import simulate_paths
-    with pytest.raises(NotImplementedError, match="one process per GPU"):
-        simulate_paths(np.zeros(3), np.eye(3) * 1e-4, np.ones(3) / 3, n_paths=8, devices=[0, 1])
+def test_multi_device_context_argument_checks(mcp_lib):
+    """mcp_ctx_create_multi: argument errors are codes, never crashes; without a GPU every request is MCP_E_NODEVICE."""
+    h = ctypes.c_void_p()
+    devs = (ctypes.c_int * 2)(0, 1)
+    assert mcp_lib.mcp_ctx_create_multi(None, 2, ctypes.byref(h)) == _ffi.MCP_E_ARG
+    assert mcp_lib.mcp_ctx_create_multi(devs, 0, ctypes.byref(h)) == _ffi.MCP_E_ARG
+    assert mcp_lib.mcp_ctx_create_multi(devs, 2, None) == _ffi.MCP_E_ARG
+    assert mcp_lib.mcp_ctx_device_count(None) == 0
+    if mcp_lib.mcp_device_count() == 0:
+        assert mcp_lib.mcp_ctx_create_multi(devs, 2, ctypes.byref(h)) == _ffi.MCP_E_NODEVICE and not h.value
+        from monte_carlo_portfolio_amd import simulate_paths
+        with pytest.raises(_ffi.McpError, match="no HIP device"):
+            simulate_paths(np.zeros(3), np.eye(3) * 1e-4, np.ones(3) / 3, n_paths=8, devices=[0, 1])
+
+
+def test_hip_errors_have_their_own_code():
+    """A HIP runtime failure is MCP_E_HIP (-5) with the HIP error string, distinct from 'no device' (-2)."""
+    text = open(os.path.join(ROOT, "include", "mcport.h")).read()
+    assert "MCP_E_HIP = -5" in text and "MCP_E_COMM = -6" in text
+    src = open(os.path.join(ROOT, "monte_carlo_portfolio_amd", "csrc", "mcp_api.cpp")).read()
+    assert "return fail(MCP_E_HIP, \"%s: %s\", #expr" in src

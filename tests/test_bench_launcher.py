@@ -1,0 +1,64 @@
+"""`python bench.py --gpus N` as typed (no external launcher): the parent touches no GPU, starts N rank processes, relays
+rank 0's JSON line and fails if any rank fails.  CPU: the ranks run the gloo rehearsal (tests/fake_kernels.py behind
+PathEngine); GPU: the real N = 1 bench through the same parent."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*args, env=None, timeout=600):
+    e = dict(os.environ, OMP_NUM_THREADS="1")
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=e, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_parent_spawns_two_ranks_over_gloo():
+    r = run_bench("--gpus", "2", "--steps", "2", "--warmup", "0", "--backend", "gloo-fake")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = last_json(r.stdout)
+    assert out["n_gpus"] == 2 and out["steps"] == 2
+    assert out["stats"]["n"] == 4000 and out["stats"]["n_tail"] == 200          # both shards reached the statistics
+
+
+def test_parent_fails_when_a_rank_fails():
+    r = run_bench("--gpus", "2", "--steps", "1", "--backend", "gloo-fake", env={"MCP_BENCH_FAIL_RANK": "1"}, timeout=120)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_parent_makes_no_gpu_call():
+    """The spawning branch runs before torch is imported (an exec/fork after a GPU call takes this pool's hosts down)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("spawn_ranks(") < main.index("import torch")
+    body = src[src.index("def spawn_ranks("):src.index("def cpu_baseline(")]
+    assert "import torch" not in body and "hip" not in body.lower() and "cuda" not in body
+
+
+def test_world_size_mismatch_is_an_error():
+    r = run_bench("--gpus", "2", "--backend", "gloo-fake", env={"WORLD_SIZE": "1", "RANK": "0"}, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+@pytest.mark.gpu
+def test_gpu_bench_through_the_spawning_parent():
+    r = run_bench("--gpus", "1", "--spawn", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = last_json(r.stdout)
+    assert out["n_gpus"] == 1 and out["unit"] == "paths/s" and out["value"] > 1e7
+    assert out["stats"]["n"] == 1_000_000 and out["stats"]["n_tail"] == 50_000
+    rf = out["roofline"]
+    assert rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1

@@ -1,0 +1,265 @@
+"""GPU tests added in round 2: the fused statistics pipeline on adversarial inputs, multi-shard contexts inside the
+library (same-device shards and a one-rank RCCL communicator), portfolio tiling under a terminal budget, configs[4] at
+its own K, and the fp32 kernel against the float64 evaluation of the spec.  All through the C ABI."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from monte_carlo_portfolio_amd import _ffi, simulate_paths, synthetic
+from monte_carlo_portfolio_amd.simulate import Context, prepare_inputs
+from oracle import mc_oracle, ref_stats
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED = synthetic.BENCH_SEED
+
+
+def check_against_reference(got, terminal, v0=1.0, compounding="simple", alpha=0.95, rf=0.0, exact_var=True):
+    want = ref_stats.path_stats(terminal, v0, compounding, alpha, rf)
+    assert got["n"] == want["n"] and got["n_tail"] == want["n_tail"]
+    if exact_var:
+        assert got["var"] == want["var"] and got["min"] == want["min"] and got["max"] == want["max"]
+    for key in ("mean", "std", "sharpe", "cvar", "sum_tail"):
+        assert got[key] == pytest.approx(want[key], rel=1e-12, abs=1e-15), key
+
+
+# ---------------------------------------------------------------- statistics pipeline on hand-made terminal values
+def stats_of_values(values, alpha=0.95, v0=1.0, compounding="simple", rf=0.0):
+    """Run pass0 -> scan -> hist -> scan -> hist -> final on caller-supplied terminal values (device-level ABI)."""
+    import torch
+    lib = _ffi.lib()
+    v = np.ascontiguousarray(values, np.float32)
+    n = v.size
+    prm = _ffi.make_params(4, 1, 1, compounding, v0, alpha, rf)
+    dev = torch.device("cuda", 0)
+    term = torch.from_numpy(v.reshape(1, n)).to(dev)
+    ws = [torch.zeros((lib.mcp_ws_bytes(w, 1) + 7) // 8, dtype=torch.int64, device=dev) for w in range(_ffi.WS_COUNT)]
+    p = [ctypes.c_void_p(t.data_ptr()) for t in ws]
+    lo, hi, g = _ffi.percentile_rank(n, alpha)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    T = ctypes.c_void_p(term.data_ptr())
+    P, R, S, H, Q, O = (p[_ffi.WS_PARTIALS], p[_ffi.WS_RECORD], p[_ffi.WS_STATE], p[_ffi.WS_HIST], p[_ffi.WS_QUANT], p[_ffi.WS_STATS])
+    for rep in range(2):                              # twice on the same buffers: the steps must leave them reusable
+        _ffi.check(lib.mcp_launch_pass0(ctypes.byref(prm), T, n, n, P, H, st))
+        _ffi.check(lib.mcp_launch_scan(ctypes.byref(prm), 0, n, lo, hi, P, H, S, R, st))
+        _ffi.check(lib.mcp_launch_hist(ctypes.byref(prm), 1, T, n, n, S, P, H, st))
+        _ffi.check(lib.mcp_launch_scan(ctypes.byref(prm), 1, n, lo, hi, P, H, S, R, st))
+        _ffi.check(lib.mcp_launch_hist(ctypes.byref(prm), 2, T, n, n, S, P, H, st))
+        _ffi.check(lib.mcp_launch_final(ctypes.byref(prm), n, g, lo, hi, P, H, S, R, Q, O, st))
+    torch.cuda.synchronize()
+    assert int(ws[_ffi.WS_HIST].abs().sum().item()) == 0          # read-and-clear protocol: histogram back to zero
+    rec = ws[_ffi.WS_STATS].cpu().numpy().view(np.uint8)[:_ffi.STATS_DTYPE.itemsize].view(_ffi.STATS_DTYPE)[0]
+    return {k: (int(rec[k]) if k in ("n", "n_tail") else float(rec[k])) for k in rec.dtype.names}
+
+
+@pytest.mark.parametrize("case", ["ties_everywhere", "two_values", "quantised", "negative", "wide_range", "hi_ties", "one", "two",
+                                  "sorted_desc", "big", "collapse_run"])
+@pytest.mark.parametrize("alpha", [0.95, 0.5, 0.999])
+def test_statistics_pipeline_on_adversarial_values(gpu_ctx, case, alpha):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(case.encode()))
+    if case == "ties_everywhere":
+        v = np.full(5000, 1.25, np.float32)
+    elif case == "two_values":
+        v = rng.choice(np.array([0.9, 1.1], np.float32), 4001)
+    elif case == "quantised":                       # heavy ties around the quantile: the tail must include every tie
+        v = np.round(rng.normal(1.0, 0.1, 20_000), 2).astype(np.float32)
+    elif case == "negative":                        # the order-preserving key must handle sign changes (log sums)
+        v = rng.normal(0.0, 1.0, 9999).astype(np.float32)
+    elif case == "wide_range":
+        v = np.exp(rng.normal(0, 4, 30_000)).astype(np.float32)
+    elif case == "collapse_run":                    # 3,000 consecutive floats near 3e-10: V/v0 - 1 maps ~4 neighbours onto one
+        v = (np.float32(3e-10).view(np.uint32) + rng.permutation(3000).astype(np.uint32)).view(np.float32)   # double: `x <= var`
+        assert np.unique(v.astype(np.float64) - 1.0).size < 1000                                              # ties run past key_hi
+    elif case == "hi_ties":                         # x_hi repeated, gamma can land var exactly on x_hi
+        v = np.concatenate([np.linspace(0.5, 0.9, 50), np.full(950, 1.0)]).astype(np.float32)
+    elif case == "one":
+        v = np.array([0.7], np.float32)
+    elif case == "two":
+        v = np.array([1.3, 0.7], np.float32)
+    elif case == "sorted_desc":
+        v = np.linspace(2.0, 0.5, 70_001).astype(np.float32)
+    else:
+        v = (1.0 + 0.2 * rng.standard_normal(3_000_017)).astype(np.float32)
+    comp = "log" if case == "negative" else "simple"
+    got = stats_of_values(v, alpha=alpha, compounding=comp, rf=0.01)
+    if case == "collapse_run":      # relative spread 1e-14: sum x^2 - sum x * mean cancels (std is not the point of this case)
+        want = ref_stats.path_stats(v, 1.0, comp, alpha, 0.01)
+        assert got["n_tail"] == want["n_tail"] and got["var"] == want["var"] and got["cvar"] == pytest.approx(want["cvar"], rel=1e-13)
+        return
+    check_against_reference(got, v, 1.0, comp, alpha, 0.01, exact_var=(comp == "simple"))
+
+
+# ---------------------------------------------------------------- shards inside the library
+@pytest.mark.parametrize("devices,P,K", [([0, 0], 10_001, 1), ([0, 0, 0], 30_000, 3), ([0] * 8, 5, 1), ([0, 0], 70_000, 20)])
+def test_same_device_shards_equal_one_device(gpu_ctx, devices, P, K):
+    """mcp_ctx_create_multi with a repeated device: the path range is sharded over logical shards that exchange
+    histograms and records exactly as distinct GPUs do over RCCL.  Order statistics, counts, terminal values identical;
+    fp64 sums up to association."""
+    mu, cov = synthetic.synthetic_market(16)
+    W = synthetic.equal_weights(16) if K == 1 else synthetic.dirichlet_weights(16, K)
+    one = simulate_paths(mu, cov, W, n_steps=25, n_paths=P, seed=11, store=True, rf=0.002, as_array=True)
+    ctx = Context(devices)
+    try:
+        assert _ffi.lib().mcp_ctx_device_count(ctx._h) == len(devices)
+        many = simulate_paths(mu, cov, W, n_steps=25, n_paths=P, seed=11, store=True, rf=0.002, as_array=True, context=ctx,
+                              devices=devices, shard="paths")
+    finally:
+        ctx.close()
+    assert np.array_equal(one[1].view(np.uint32), many[1].view(np.uint32))            # terminal values, in path order
+    for key in ("n", "n_tail", "var", "x_lo", "x_hi", "min", "max"):
+        assert np.array_equal(one[0][key], many[0][key]), key
+    for key in ("mean", "std", "sharpe", "cvar", "sum_tail"):
+        np.testing.assert_allclose(many[0][key], one[0][key], rtol=1e-13, atol=1e-16)
+    mu32, L, W32 = prepare_inputs(mu, cov, W)
+    ref = mc_oracle.simulate(mu32, L, W32, 25, P, 11)
+    for k in range(K):
+        check_against_reference({n: many[0][n][k] for n in many[0].dtype.names}, ref[k], rf=0.002)
+
+
+def test_portfolio_sharding_inside_the_library(gpu_ctx):
+    mu, cov = synthetic.synthetic_market(16)
+    W = synthetic.dirichlet_weights(16, 1100)
+    one = simulate_paths(mu, cov, W, n_steps=12, n_paths=4096, seed=3, as_array=True)
+    ctx = Context([0, 0, 0])
+    try:
+        many = simulate_paths(mu, cov, W, n_steps=12, n_paths=4096, seed=3, as_array=True, context=ctx, devices=[0, 0, 0],
+                              shard="portfolios")
+    finally:
+        ctx.close()
+    assert one.tobytes() == many.tobytes()             # same kernels on the same inputs per portfolio: identical records
+    assert int(np.argmax(one["sharpe"])) == int(np.argmax(many["sharpe"]))
+
+
+def test_rccl_path_with_a_one_rank_communicator(gpu_ctx):
+    """MCP_FORCE_RCCL=1: ncclCommInitAll / ncclAllReduce / ncclAllGather / group calls are really issued (one rank), in a
+    child process so the environment variable is seen at context creation."""
+    code = f"""
+import sys; sys.path.insert(0, {ROOT!r})
+import numpy as np
+from monte_carlo_portfolio_amd import _ffi, simulate_paths, synthetic
+from monte_carlo_portfolio_amd.simulate import Context
+_ffi.preload_rccl()
+mu, cov = synthetic.synthetic_market(16); w = synthetic.equal_weights(16)
+ctx = Context(0)
+r = simulate_paths(mu, cov, w, n_steps=30, n_paths=50_000, seed=5, context=ctx)
+print(r["n"], r["n_tail"], r["var"].hex(), r["cvar"].hex(), r["sharpe"].hex())
+"""
+    outs = []
+    for force in ("0", "1"):
+        env = dict(os.environ, MCP_FORCE_RCCL=force)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(r.stdout.strip().splitlines()[-1].split())
+    assert outs[0][:3] == outs[1][:3] and outs[0][0] == "50000" and outs[0][1] == "2500"
+    for a, b in zip(outs[0][3:], outs[1][3:]):
+        assert float.fromhex(a) == pytest.approx(float.fromhex(b), rel=1e-14)
+
+
+def test_terminal_budget_tiles_the_portfolios(gpu_ctx):
+    """V_T[K x paths] is not materialised whole -- with a small budget the sweep runs in tiles of
+    512 portfolios and must give the records of the untiled run, bit for bit."""
+    mu, cov = synthetic.synthetic_market(16)
+    W = synthetic.dirichlet_weights(16, 1700)
+    P = 8192
+    whole = simulate_paths(mu, cov, W, n_steps=10, n_paths=P, seed=9, as_array=True, store=True)
+    ctx = Context(0, terminal_budget=600 * P * 4)          # room for 600 portfolios -> tiles of 512, 512, 512, 164
+    try:
+        tiled = simulate_paths(mu, cov, W, n_steps=10, n_paths=P, seed=9, as_array=True, store=True, context=ctx)
+    finally:
+        ctx.close()
+    assert whole[0].tobytes() == tiled[0].tobytes()
+    assert np.array_equal(whole[1].view(np.uint32), tiled[1].view(np.uint32))
+
+
+def test_more_portfolios_than_a_grid_dimension(gpu_ctx):
+    """K > 65,535 (the old gridDim.y limit): every launch indexes portfolios through blockIdx.x."""
+    mu, cov = synthetic.synthetic_market(4)
+    K = 66_000
+    W = synthetic.dirichlet_weights(4, K)
+    st = simulate_paths(mu, cov, W, n_steps=3, n_paths=256, seed=2, as_array=True)
+    assert st.shape == (K,) and np.all(st["n"] == 256) and np.all(st["n_tail"] == 13)
+    mu32, L, W32 = prepare_inputs(mu, cov, W)
+    for k in (0, 65_535, 65_999):
+        ref = mc_oracle.simulate(mu32, L, W32[k:k + 1], 3, 256, 2)
+        check_against_reference({n: st[n][k] for n in st.dtype.names}, ref[0])
+
+
+# ---------------------------------------------------------------- configs[4] at its own K
+def test_config4_ten_thousand_portfolios(gpu_ctx):
+    """BASELINE configs[4]: 10,000 Dirichlet portfolios x 16 assets x 252 steps on common random numbers, 65,536 paths
+    (the full 10^6 is the same code per 64-path workgroup; the driver-run test keeps the box time bounded).  n / n_tail
+    exact for all K; every statistic against the oracle on sampled portfolios; the max-Sharpe / min-VaR indices against
+    the oracle restricted to the candidates near the optimum."""
+    N, T, P, K = 16, 252, 65_536, 10_000
+    mu, cov = synthetic.synthetic_market(N)
+    W = synthetic.dirichlet_weights(N, K)
+    st = simulate_paths(mu, cov, W, n_steps=T, n_paths=P, seed=SEED, as_array=True, rf=0.0)
+    lo, hi, _ = _ffi.percentile_rank(P, 0.95)
+    assert st.shape == (K,) and np.all(st["n"] == P) and np.all(st["n_tail"] >= lo + 1) and np.all(st["n_tail"] <= lo + 3)
+    assert np.all(st["x_lo"] <= st["var"]) and np.all(st["var"] <= st["x_hi"]) and np.all(st["cvar"] <= st["var"])
+    assert np.all(st["min"] <= st["x_lo"]) and np.all(np.isfinite(st["sharpe"]))
+    mu32, L, W32 = prepare_inputs(mu, cov, W)
+    best = np.argsort(-st["sharpe"])[:6]
+    safest = np.argsort(st["var"])[-3:]
+    sample = sorted(set([0, 511, 512, 4999, 9999]) | set(int(b) for b in best) | set(int(s) for s in safest))
+    ref = mc_oracle.simulate(mu32, L, W32[sample], T, P, SEED)
+    want_sharpe = {}
+    for i, k in enumerate(sample):
+        check_against_reference({n: st[n][k] for n in st.dtype.names}, ref[i])
+        want_sharpe[k] = ref_stats.path_stats(ref[i])["sharpe"]
+    # argmax over portfolios: the GPU's winner must be the oracle's winner among the top candidates (exact index)
+    assert int(np.argmax(st["sharpe"])) == max((int(b) for b in best), key=lambda k: want_sharpe[k])
+    # analytic cross-check of the whole field: mean_k = (1 + w_k.mu)^T - 1 within 5 standard errors
+    ana = (1.0 + W32.astype(np.float64) @ mu32.astype(np.float64)) ** T - 1.0
+    assert np.all(np.abs(st["mean"] - ana) < 5 * st["std"] / np.sqrt(P))
+
+
+# ---------------------------------------------------------------- fp32 kernel against the float64 evaluation of the spec
+def test_gpu_statistics_match_float64_evaluation_at_one_million_paths(gpu_ctx):
+    """north_star: Sharpe / VaR within 1e-6 of the NumPy (float64) reference on identical seeds.  The float64 oracle
+    evaluates the same draws in binary64 (the reference's arithmetic, app.py:258-263, 708-713); bench.py reports the same
+    differences as var_abs_err_f64 / sharpe_rel_err_f64."""
+    N, T, P = 16, 252, 1_000_000
+    mu, cov = synthetic.synthetic_market(N)
+    w = synthetic.equal_weights(N)
+    g = simulate_paths(mu, cov, w, n_steps=T, n_paths=P, seed=SEED)
+    mu32, L, W32 = prepare_inputs(mu, cov, w)
+    x64 = mc_oracle.simulate_f64(mu32, L, W32, T, P, SEED)[0] - 1.0
+    want = {"mean": x64.mean(), "std": x64.std(ddof=1), "var": ref_stats.var(x64), "cvar": ref_stats.cvar(x64)}
+    want["sharpe"] = want["mean"] / want["std"]
+    for key in ("mean", "std", "var", "cvar"):
+        assert abs(g[key] - want[key]) < 1e-6, (key, g[key], want[key])
+    assert abs(g["sharpe"] - want["sharpe"]) / abs(want["sharpe"]) < 1e-6
+    assert g["n_tail"] == int((x64 <= want["var"]).sum())
+
+
+@pytest.mark.parametrize("N", [3, 7, 13, 16])
+def test_log_compounding_matches_the_analytic_normal_law(gpu_ctx, N):
+    """Spec-independent check of the covariance structure (Cholesky row-pair packing, asset <-> Philox word layout):
+    with compounding='log', S_T ~ N(T w.mu, T w' Sigma w) exactly.  std, the 5 % quantile and the correlation between
+    two portfolios must agree with the float64 analytic values within 5 standard errors (N not a multiple of 4 included)."""
+    from scipy.special import ndtri
+    T, P = 40, 400_000
+    mu, cov = synthetic.synthetic_market(N)
+    W = synthetic.dirichlet_weights(N, 2)
+    mu32, L, W32 = prepare_inputs(mu, cov, W)
+    st, term = simulate_paths(mu, cov, W, n_steps=T, n_paths=P, seed=123, compounding="log", as_array=True, store=True)
+    S = term.astype(np.float64)
+    Sig = L.astype(np.float64) @ L.astype(np.float64).T
+    w64 = W32.astype(np.float64)
+    for k in range(2):
+        m = T * w64[k] @ mu32.astype(np.float64)
+        sd = np.sqrt(T * w64[k] @ Sig @ w64[k])
+        assert abs(S[k].mean() - m) < 5 * sd / np.sqrt(P)
+        assert abs(S[k].std(ddof=1) / sd - 1) < 5 / np.sqrt(2 * P)
+        q = np.quantile(S[k], 0.05)
+        se_q = np.sqrt(0.05 * 0.95 / P) / (np.exp(-0.5 * ndtri(0.05) ** 2) / np.sqrt(2 * np.pi)) * sd
+        assert abs(q - (m + sd * ndtri(0.05))) < 5 * se_q
+    rho = (w64[0] @ Sig @ w64[1]) / np.sqrt((w64[0] @ Sig @ w64[0]) * (w64[1] @ Sig @ w64[1]))
+    got = np.corrcoef(S[0], S[1])[0, 1]
+    assert abs(got - rho) < 5 * (1 - rho ** 2) / np.sqrt(P) + 1e-6
