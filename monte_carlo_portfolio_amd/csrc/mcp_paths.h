@@ -63,7 +63,8 @@ constexpr int PATH_BLOCK = 256;
 
 // NB = N4/4 Philox blocks per path-step; KT portfolios per pass; PPT paths per lane; FOLD: rho = c + v.z with
 // v = L^T w precomputed on the host (SPEC.md 4.1, one portfolio) instead of the triangular GEMV.
-template <int NB, int KT, int PPT, bool NATIVE, bool FOLD = false>
+// LOGC: compounding mode at compile time (as a run-time flag the compiler if-converts the step into fma + add + select).
+template <int NB, int KT, int PPT, bool NATIVE, bool FOLD = false, bool LOGC = false>
 __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ? MCP_MIN_WAVES : 1) mc_paths_kernel(const PathArgs a) {
   constexpr int N4 = 4 * NB;
   // wave-uniform parameters through the constant address space -> s_load_dword* into SGPRs
@@ -73,11 +74,12 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
   cfloat_p Wk = mu + N4 + N4 * (N4 / 2 + 1) + (size_t)a.k_begin * N4;
   const int kt = min(KT, a.n_portfolios - a.k_begin);   // live portfolios in this pass (uniform)
   // inverse-CDF table: 16.5 KiB of LDS per block, filled once from the device-resident copy
-  __shared__ float4 s_tab[ICDF_ENTRIES];
+  __shared__ float4 s_tab[ICDF_LDS_ENTRIES];
   if constexpr (!NATIVE) {
-    for (int i = threadIdx.x; i < ICDF_ENTRIES; i += PATH_BLOCK) s_tab[i] = a.tables[i];
+    for (int i = threadIdx.x; i < ICDF_ENTRIES; i += PATH_BLOCK) s_tab[ICDF_PAD + i] = a.tables[i];
     __syncthreads();
   }
+  const IcdfConsts kc = icdf_consts();
   PhiloxKeys ks = philox_keys((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
 #if MCP_EXP_VKEYS
   // pin the 20 round keys in VGPRs: an SGPR operand halves the issue rate of the xor (profiles/r01_valu_rates.txt)
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
   for (int r = 0; r < 10; r++) { asm volatile("" : "+v"(ks.k0[r])); asm volatile("" : "+v"(ks.k1[r])); }
 #endif
   const int T = a.n_steps;
-  const bool logc = a.compounding == MCP_COMPOUND_LOG;
+  constexpr bool logc = LOGC;
 
   const uint64_t tile = (uint64_t)PATH_BLOCK * PPT;
   const uint64_t n_tiles = (a.n_paths + tile - 1) / tile;
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
         for (int e = 0; e < PPT; e++) {
           uint32_t x[4];
           philox4x32_10(blk, 0u, plo[e], phi[e], ks, x);
-          block_normals<NATIVE>(x, s_tab, z[e][0 * NB + q], z[e][1 * NB + q], z[e][2 * NB + q], z[e][3 * NB + q]);
+          block_normals<NATIVE>(x, s_tab, kc, z[e][0 * NB + q], z[e][1 * NB + q], z[e][2 * NB + q], z[e][3 * NB + q]);
         }
       }
       float rho[PPT][KT];

@@ -22,9 +22,12 @@ static size_t lds_pad() {
   return pad;
 }
 
-template <int KT, int PPT, bool NATIVE>
+template <int KT, int PPT, bool NATIVE, bool FOLD = false>
 static hipError_t go(const PathArgs& args, int grid, hipStream_t stream) {
-  mc_paths_kernel<MCP_NB, KT, PPT, NATIVE><<<grid, PATH_BLOCK, lds_pad(), stream>>>(args);
+  if (args.compounding == MCP_COMPOUND_LOG)
+    mc_paths_kernel<MCP_NB, KT, PPT, NATIVE, FOLD, true><<<grid, PATH_BLOCK, lds_pad(), stream>>>(args);
+  else
+    mc_paths_kernel<MCP_NB, KT, PPT, NATIVE, FOLD, false><<<grid, PATH_BLOCK, lds_pad(), stream>>>(args);
   return hipGetLastError();
 }
 
@@ -32,7 +35,7 @@ hipError_t MCP_CAT(launch_paths_nb, MCP_NB)(int variant, const PathArgs& args, i
   switch (variant) {
     case 0: return go<1, 1, false>(args, grid, stream);
     case VAR_NATIVE: return go<1, 1, true>(args, grid, stream);
-    case VAR_FOLD: mc_paths_kernel<MCP_NB, 1, 1, false, true><<<grid, PATH_BLOCK, lds_pad(), stream>>>(args); return hipGetLastError();
+    case VAR_FOLD: return go<1, 1, false, true>(args, grid, stream);
     case VAR_KT8: return go<8, 1, false>(args, grid, stream);
     case VAR_KT8 | VAR_NATIVE: return go<8, 1, true>(args, grid, stream);
 #if MCP_NB <= 4 && defined(MCP_EXP_PPT2)      // two paths per lane: measured 3 % slower (129 VGPRs), kept behind a build flag

@@ -64,6 +64,7 @@ hipError_t launch_stats(const mcp_params& prm, int K, int world, const mcp_recor
                         mcp_stats* out, hipStream_t s);
 // out[i] = sum over the `nsrc` buffers src[0..nsrc) (u64 words), written to every buffer: the exchange between
 // several logical shards resident on ONE device (mcp_ctx_create_multi with a repeated device)
+hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);
 hipError_t launch_sum_u64(unsigned long long* const* bufs, int nsrc, size_t words, hipStream_t s);
 
 hipError_t launch_sweep_hist(int N, int R, int P, const double* returns, const double* mean, const double* cov,

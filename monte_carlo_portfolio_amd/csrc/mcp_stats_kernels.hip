@@ -51,11 +51,11 @@ __device__ __forceinline__ void lds_hist_add(uint32_t* h, uint32_t digit, bool a
   if (active) atomicAdd(&h[digit], 1u);
 }
 
-// blocks per portfolio of a streaming pass over n values: >= 1 Ki values per 256-thread block, at most stream_slots(K).
+// blocks per portfolio of a streaming pass over n values: >= 4 Ki values per 256-thread block, at most stream_slots(K).
 // The passes are latency-bound (a load, an fp64 divide, an LDS atomic per element and lane), so they want every wave
 // slot of the chip before they want long per-thread loops (measured: 57 -> 9 us for pass 0 at 10^6 values).
 static int stream_grid(uint64_t n, int K) {
-  static const uint64_t per = [] { const char* e = getenv("MCP_STREAM_ELEMS"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 1024); }();
+  static const uint64_t per = [] { const char* e = getenv("MCP_STREAM_ELEMS"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 4096); }();
   uint64_t g = (n + per - 1) / per;
   if (g < 1) g = 1;
   const uint64_t cap = (uint64_t)stream_slots(K);
@@ -236,8 +236,10 @@ __global__ void __launch_bounds__(SB) scan_kernel(int pass, uint64_t rank_lo, ui
     unsigned long long c[PER], tot = 0;
 #pragma unroll
     for (int i = 0; i < PER; i++) { c[i] = hh[threadIdx.x * PER + i]; tot += c[i]; }
-    const unsigned long long before = block_exclusive_scan(tot, wtot);
+    // read the state BEFORE the barriers of the scan: the owning thread rewrites it right after them, and a wave that
+    // read it late would see the new prefix and descend a second time
     SelectState st = pass == 0 ? SelectState{0u, 0u, w ? rank_hi : rank_lo} : state[2 * k + w];
+    const unsigned long long before = block_exclusive_scan(tot, wtot);
     descend(pass, c, tot, before, st, &state[2 * k + w]);
     if (pass != 0 || w == 1) {                      // consumed: clear for the next pass (read-and-clear protocol)
 #pragma unroll
@@ -377,10 +379,11 @@ __global__ void __launch_bounds__(SB) sum_u64_kernel(PtrList l, size_t words) {
 // to hit edge inputs (both ends of every octave, u == 1/2, the deepest tail).
 __global__ void __launch_bounds__(256) normals_kernel(const uint32_t* __restrict__ x, uint64_t n,
                                                       const float4* __restrict__ table, float* __restrict__ z) {
-  __shared__ float4 s_tab[ICDF_ENTRIES];
-  for (int i = threadIdx.x; i < ICDF_ENTRIES; i += 256) s_tab[i] = table[i];
+  __shared__ float4 s_tab[ICDF_LDS_ENTRIES];
+  for (int i = threadIdx.x; i < ICDF_ENTRIES; i += 256) s_tab[ICDF_PAD + i] = table[i];
   __syncthreads();
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) z[i] = normal_icdf(x[i], s_tab);
+  const IcdfConsts kc = icdf_consts();
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) z[i] = normal_icdf(x[i], s_tab, kc);
 }
 
 hipError_t launch_normals(const uint32_t* x, uint64_t n, const float4* table, float* z, hipStream_t s) {
@@ -427,6 +430,21 @@ hipError_t launch_final(const mcp_params& prm, int K, uint64_t n, double gamma, 
 hipError_t launch_stats(const mcp_params& prm, int K, int world, const mcp_record* gathered, const Quantile* quant,
                         mcp_stats* out, hipStream_t s) {
   stats_kernel<<<(K + 63) / 64, 64, 0, s>>>(prm, K, world, gathered, quant, out);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(SB) zero_u64_kernel(unsigned long long* __restrict__ p, size_t words) {
+  for (size_t i = (size_t)blockIdx.x * SB + threadIdx.x; i < words; i += (size_t)gridDim.x * SB) p[i] = 0ull;
+}
+
+// A plain kernel instead of hipMemsetAsync: ordered like any other launch on the stream, and safe inside a hipGraph
+// (a captured memset node replayed wrongly on the ROCm 7.0 runtime bundled with torch).  bytes is a multiple of 8.
+hipError_t launch_zero(void* p, size_t bytes, hipStream_t s) {
+  const size_t words = bytes / 8;
+  size_t g = (words + SB - 1) / SB;
+  if (g < 1) g = 1;
+  if (g > 4096) g = 4096;
+  zero_u64_kernel<<<(unsigned)g, SB, 0, s>>>((unsigned long long*)p, words);
   return hipGetLastError();
 }
 

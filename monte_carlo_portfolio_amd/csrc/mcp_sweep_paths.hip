@@ -36,11 +36,12 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
   cfloat_p Lp = mu + N4;
   const float* __restrict__ Wg = a.packed + N4 + N4 * (N4 / 2 + 1);   // [Kpad][N4], rows >= K are zero
 
-  __shared__ float4 s_tab[ICDF_ENTRIES];
+  __shared__ float4 s_tab[ICDF_LDS_ENTRIES];
   if constexpr (!NATIVE) {
-    for (int i = threadIdx.x; i < ICDF_ENTRIES; i += PATH_BLOCK) s_tab[i] = a.tables[i];
+    for (int i = threadIdx.x; i < ICDF_ENTRIES; i += PATH_BLOCK) s_tab[ICDF_PAD + i] = a.tables[i];
     __syncthreads();
   }
+  const IcdfConsts kc = icdf_consts();
   const PhiloxKeys ks = philox_keys((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t p = ((uint64_t)blockIdx.x * (PATH_BLOCK / 64) + wave) * 64 + lane;     // local path of this lane (draw)
@@ -71,7 +72,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
     for (int q = 0; q < NB; q++) {
       uint32_t x[4];
       philox4x32_10((uint32_t)t * NB + q, 0u, plo, phi, ks, x);
-      block_normals<NATIVE>(x, s_tab, z[0 * NB + q], z[1 * NB + q], z[2 * NB + q], z[3 * NB + q]);
+      block_normals<NATIVE>(x, s_tab, kc, z[0 * NB + q], z[1 * NB + q], z[2 * NB + q], z[3 * NB + q]);
     }
     float r[N4];
 #pragma unroll
@@ -139,12 +140,13 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
   cfloat_p Lp = mu + N4;
   const float* __restrict__ Wg = a.packed + N4 + N4 * (N4 / 2 + 1);
 
-  __shared__ float4 s_tab[ICDF_ENTRIES];
+  __shared__ float4 s_tab[ICDF_LDS_ENTRIES];
   __shared__ float s_z[N4][64], s_r[N4][64];
   if constexpr (!NATIVE) {
-    for (int i = threadIdx.x; i < ICDF_ENTRIES; i += PATH_BLOCK) s_tab[i] = a.tables[i];
+    for (int i = threadIdx.x; i < ICDF_ENTRIES; i += PATH_BLOCK) s_tab[ICDF_PAD + i] = a.tables[i];
   }
   __syncthreads();
+  const IcdfConsts kc = icdf_consts();
   const PhiloxKeys ks = philox_keys((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t p = (uint64_t)blockIdx.x * 64 + lane;             // all four waves: the same 64 paths
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
         uint32_t x[4];
         philox4x32_10((uint32_t)t * NB + q, 0u, plo, phi, ks, x);
         float z0, z1, z2, z3;
-        block_normals<NATIVE>(x, s_tab, z0, z1, z2, z3);
+        block_normals<NATIVE>(x, s_tab, kc, z0, z1, z2, z3);
         s_z[0 * NB + q][lane] = z0;
         s_z[1 * NB + q][lane] = z1;
         s_z[2 * NB + q][lane] = z2;

@@ -94,6 +94,45 @@ def test_statistics_pipeline_on_adversarial_values(gpu_ctx, case, alpha):
     check_against_reference(got, v, 1.0, comp, alpha, 0.01, exact_var=(comp == "simple"))
 
 
+@pytest.mark.parametrize("K,n", [(2000, 1000), (1100, 4096), (37, 70_001)])
+def test_statistics_pipeline_many_portfolios_at_once(gpu_ctx, K, n):
+    """K portfolios in one launch chain, three times on the same buffers (run-to-run identical, every VaR bit-equal to
+    np.percentile).  Regression: a wave that read the select state after its owner had rewritten it descended twice."""
+    import torch
+    lib = _ffi.lib()
+    rng = np.random.default_rng(K)
+    v = (1.0 + 0.05 * rng.standard_normal((K, n))).astype(np.float32)
+    prm = _ffi.make_params(4, 1, K)
+    dev = torch.device("cuda", 0)
+    term = torch.from_numpy(v).to(dev)
+    ws = [torch.zeros((lib.mcp_ws_bytes(w, K) + 7) // 8, dtype=torch.int64, device=dev) for w in range(_ffi.WS_COUNT)]
+    p = [ctypes.c_void_p(t.data_ptr()) for t in ws]
+    lo, hi, g = _ffi.percentile_rank(n, 0.95)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    T, B = ctypes.c_void_p(term.data_ptr()), ctypes.byref(prm)
+    P, R, S, H, Q, O = (p[_ffi.WS_PARTIALS], p[_ffi.WS_RECORD], p[_ffi.WS_STATE], p[_ffi.WS_HIST], p[_ffi.WS_QUANT], p[_ffi.WS_STATS])
+    x = v.astype(np.float64) - 1.0
+    want_var = np.percentile(x, (1 - 0.95) * 100, axis=1)
+    first = None
+    for rep in range(3):
+        _ffi.check(lib.mcp_launch_pass0(B, T, n, n, P, H, st))
+        _ffi.check(lib.mcp_launch_scan(B, 0, n, lo, hi, P, H, S, R, st))
+        _ffi.check(lib.mcp_launch_hist(B, 1, T, n, n, S, P, H, st))
+        _ffi.check(lib.mcp_launch_scan(B, 1, n, lo, hi, P, H, S, R, st))
+        _ffi.check(lib.mcp_launch_hist(B, 2, T, n, n, S, P, H, st))
+        _ffi.check(lib.mcp_launch_final(B, n, g, lo, hi, P, H, S, R, Q, O, st))
+        torch.cuda.synchronize()
+        rec = ws[_ffi.WS_STATS].cpu().numpy().view(np.uint8)[:K * _ffi.STATS_DTYPE.itemsize].view(_ffi.STATS_DTYPE).copy()
+        assert np.array_equal(rec["var"], want_var)
+        assert np.array_equal(rec["n_tail"], (x <= want_var[:, None]).sum(axis=1))
+        np.testing.assert_allclose(rec["cvar"], np.where(x <= want_var[:, None], x, 0.0).sum(axis=1) / rec["n_tail"], rtol=1e-12)
+        np.testing.assert_allclose(rec["mean"], x.mean(axis=1), rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(rec["std"], x.std(axis=1, ddof=1), rtol=1e-11)
+        assert first is None or first.tobytes() == rec.tobytes()          # deterministic: fixed-order sums, integer histograms
+        first = rec
+    assert int((ws[_ffi.WS_HIST] != 0).sum().item()) == 0
+
+
 # ---------------------------------------------------------------- shards inside the library
 @pytest.mark.parametrize("devices,P,K", [([0, 0], 10_001, 1), ([0, 0, 0], 30_000, 3), ([0] * 8, 5, 1), ([0, 0], 70_000, 20)])
 def test_same_device_shards_equal_one_device(gpu_ctx, devices, P, K):
@@ -131,7 +170,10 @@ def test_portfolio_sharding_inside_the_library(gpu_ctx):
                               shard="portfolios")
     finally:
         ctx.close()
-    assert one.tobytes() == many.tobytes()             # same kernels on the same inputs per portfolio: identical records
+    for key in ("n", "n_tail", "var", "x_lo", "x_hi", "min", "max"):      # order statistics and counts: exact
+        assert np.array_equal(one[key], many[key]), key
+    for key in ("mean", "std", "sharpe", "cvar", "sum_tail"):           # fp64 sums: the block count per portfolio depends on K
+        np.testing.assert_allclose(many[key], one[key], rtol=1e-13, atol=1e-16)
     assert int(np.argmax(one["sharpe"])) == int(np.argmax(many["sharpe"]))
 
 
@@ -172,7 +214,10 @@ def test_terminal_budget_tiles_the_portfolios(gpu_ctx):
         tiled = simulate_paths(mu, cov, W, n_steps=10, n_paths=P, seed=9, as_array=True, store=True, context=ctx)
     finally:
         ctx.close()
-    assert whole[0].tobytes() == tiled[0].tobytes()
+    for key in ("n", "n_tail", "var", "x_lo", "x_hi", "min", "max"):
+        assert np.array_equal(whole[0][key], tiled[0][key]), key
+    for key in ("mean", "std", "sharpe", "cvar", "sum_tail"):
+        np.testing.assert_allclose(tiled[0][key], whole[0][key], rtol=1e-13, atol=1e-16)
     assert np.array_equal(whole[1].view(np.uint32), tiled[1].view(np.uint32))
 
 
@@ -182,9 +227,11 @@ def test_more_portfolios_than_a_grid_dimension(gpu_ctx):
     K = 66_000
     W = synthetic.dirichlet_weights(4, K)
     st = simulate_paths(mu, cov, W, n_steps=3, n_paths=256, seed=2, as_array=True)
-    assert st.shape == (K,) and np.all(st["n"] == 256) and np.all(st["n_tail"] == 13)
+    assert st.shape == (K,) and np.all(st["n"] == 256) and np.all(st["n_tail"] >= 13)
+    odd = np.nonzero(st["n_tail"] != 13)[0]              # ties at the quantile (x[x <= var] then holds more than lo + 1 values)
+    assert len(odd) < 200
     mu32, L, W32 = prepare_inputs(mu, cov, W)
-    for k in (0, 65_535, 65_999):
+    for k in [0, 65_535, 65_999] + [int(o) for o in odd[:12]]:
         ref = mc_oracle.simulate(mu32, L, W32[k:k + 1], 3, 256, 2)
         check_against_reference({n: st[n][k] for n in st.dtype.names}, ref[0])
 
