@@ -184,6 +184,9 @@ def main():
                     help="side benchmark, NOT the BASELINE metric: configs[4] shape (10,000 Dirichlet portfolios, 16 assets, "
                          "252 steps, --sweep-paths paths), portfolio-sharded over the ranks, MFMA kernel")
     ap.add_argument("--sweep-paths", type=int, default=131072)
+    ap.add_argument("--config3", action="store_true",
+                    help="side benchmark, NOT the BASELINE metric: configs[3] shape (64 assets, 1260 steps, --config3-paths paths per GPU)")
+    ap.add_argument("--config3-paths", type=int, default=10_000_000)
     ap.add_argument("--paths-per-gpu", type=int, default=PATHS_PER_GPU,
                     help="default 1,000,000 = BASELINE configs[1]; 12,500,000 is one GPU's shard of configs[2]")
     args = ap.parse_args()
@@ -243,6 +246,36 @@ def main():
                               "config": {"workload": f"10,000 portfolios x {args.sweep_paths} paths x 252 steps, 16 assets, portfolio-sharded"},
                               "wr_product_tflops": flops / dt / 1e12, "opt_idx_max_sharpe": int(np.argmax(st["sharpe"])),
                               "configs4_seconds_extrapolated": dt * 1e6 / args.sweep_paths}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if args.config3:
+        N3, T3, P3 = 64, 1260, args.config3_paths
+        mu3, cov3 = synthetic.synthetic_market(N3)
+        mu32, L, W32 = prepare_inputs(mu3, cov3, synthetic.equal_weights(N3))
+        eng = PathEngine(mu32, L, W32, T3, P3, group=group, world_size=world, rank=rank, native_math=args.native_math, pipeline=False)
+        for _ in range(max(args.warmup, 1)):
+            eng.step(seed)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.step(seed)
+        st = eng.stats()[0]
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        if rank == 0:
+            flops = T3 * (N3 * N3 + 3 * N3 + 2)                    # 5,405,400 per path
+            tf = flops * P3 * world / dt / 1e12
+            print(json.dumps({"metric": "paths/s (side benchmark, configs[3] shape)", "value": P3 * world / dt, "unit": "paths/s",
+                              "n_gpus": world, "steps": args.steps, "ms_per_step": dt * 1e3, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": f"configs[3]: 64 assets, {P3:,} paths per GPU, 1260 steps; triangular GEMV as "
+                                                     "SGPR-fed v_pk_fma_f32 (DESIGN.md section 4: fp32 MFMA shares the FMA pipe)"},
+                              "model_tflops": tf, "frac_of_fp32_vector_peak": tf / world / FP32_VECTOR_PEAK_TFLOPS,
+                              "stats": {"mean": float(st["mean"]), "std": float(st["std"]), "var95": float(st["var"]), "n": int(st["n"])}}))
         if world > 1:
             dist.destroy_process_group()
         return

@@ -23,6 +23,9 @@
 #ifndef MCP_EXP_VKEYS
 #define MCP_EXP_VKEYS 1
 #endif
+#ifndef MCP_EXP_LDSPAR      // 1: drift from LDS; 2: drift and (one portfolio) weights from LDS
+#define MCP_EXP_LDSPAR 0
+#endif
 
 namespace mcp {
 
@@ -77,8 +80,17 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
   __shared__ float4 s_tab[ICDF_LDS_ENTRIES];
   if constexpr (!NATIVE) {
     for (int i = threadIdx.x; i < ICDF_ENTRIES; i += PATH_BLOCK) s_tab[ICDF_PAD + i] = a.tables[i];
-    __syncthreads();
   }
+  // The 512 B of padding in front of the table hold the drift (and, for one portfolio, the weights): read from LDS they
+  // land in VGPRs without a VALU instruction (a v_mov from an SGPR costs an issue slot, an SGPR operand halves the
+  // issue rate of the weight-dot FMAs).
+  constexpr bool LDS_MU = MCP_EXP_LDSPAR >= 1 && !NATIVE && !FOLD;
+  constexpr bool LDS_W = MCP_EXP_LDSPAR >= 2 && !NATIVE && !FOLD && KT == 1;
+  float* const s_par0 = (float*)&s_tab[0];
+  if constexpr (LDS_MU) {
+    if (threadIdx.x < N4) { s_par0[threadIdx.x] = mu[threadIdx.x]; if (LDS_W) s_par0[N4 + threadIdx.x] = Wk[threadIdx.x]; }
+  }
+  if constexpr (!NATIVE) __syncthreads();
   const IcdfConsts kc = icdf_consts();
   PhiloxKeys ks = philox_keys((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
 #if MCP_EXP_VKEYS
@@ -109,6 +121,9 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
     for (int t = 0; t < T; t++) {
       // keep the (loop-invariant) parameter loads inside the step: hoisted, they would pin ~170 registers
       asm volatile("" : "+s"(mu), "+s"(Lp), "+s"(Wk));
+      uint32_t par_off = 0;                                        // opaque zero: keeps the LDS reads inside the step too
+      if constexpr (LDS_MU) asm volatile("" : "+v"(par_off));
+      const float* s_par = s_par0 + par_off;
       float z[PPT][N4];
 #pragma unroll
       for (int q = 0; q < NB; q++) {
@@ -142,7 +157,9 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
 #pragma unroll
       for (int m = 0; m < N4 / 2; m++) {
         f32x2 acc[PPT];
-        const f32x2 mu2 = {mu[2 * m], mu[2 * m + 1]};
+        f32x2 mu2;
+        if constexpr (LDS_MU) mu2 = *(const f32x2*)&s_par[2 * m];
+        else mu2 = f32x2{mu[2 * m], mu[2 * m + 1]};
 #pragma unroll
         for (int e = 0; e < PPT; e++) acc[e] = mu2;
 #pragma unroll
@@ -156,7 +173,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
           const int i = 2 * m + h;
 #pragma unroll
           for (int k = 0; k < KT; k++) {
-            const float wki = Wk[k * N4 + i];              // rows >= kt are zero-padded by pack_params
+            const float wki = LDS_W ? s_par[N4 + i] : Wk[k * N4 + i];   // rows >= kt are zero-padded by pack_params
 #pragma unroll
             for (int e = 0; e < PPT; e++) rho[e][k] = fma32(wki, h ? acc[e].y : acc[e].x, rho[e][k]);
           }

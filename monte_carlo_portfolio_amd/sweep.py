@@ -47,10 +47,11 @@ def sweep_inputs(returns_df, annual_factor):
         mean = (returns_df.mean() * annual_factor).to_numpy(dtype=np.float64)
         cov = (returns_df.cov() * annual_factor).to_numpy(dtype=np.float64)
         R = returns_df.to_numpy(dtype=np.float64)
-    else:
+    else:                                                # plain [R, N] array (the pandas-free ingest): the same numbers,
+        from .ingest_np import pandas_cov, pandas_mean   # bit for bit, as the DataFrame route (tests/test_ingest_np.py)
         R = np.asarray(returns_df, np.float64)
-        mean = R.mean(axis=0) * annual_factor
-        cov = np.atleast_2d(np.cov(R, rowvar=False, ddof=1)) * annual_factor
+        mean = pandas_mean(R) * annual_factor
+        cov = pandas_cov(R) * annual_factor
     return np.ascontiguousarray(R), np.ascontiguousarray(mean), np.ascontiguousarray(cov)
 
 

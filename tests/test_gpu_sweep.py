@@ -123,3 +123,25 @@ def test_example_pipeline_runs_end_to_end(gpu_ctx, capsys):
     assert "opt_idx" in out and sim["n"] == 50_000 and sim["var"] < sim["mean"] and sim["cvar"] <= sim["var"]
     assert res["Monte Carlo"]["all_weights"].shape == (2500, 3) and "Avalanche Historical Data" in out
     assert set(res) == set(sweep.METHODS)
+
+
+def test_pandas_free_pipeline_reaches_the_reference_optimum(gpu_ctx):
+    """SURVEY.md section 8f-2 end to end: CSV files -> ingest_np (no pandas) -> returns matrix -> GPU sweep, against the
+    reference's own run: identical mean / covariance bits, identical optimum index for every method."""
+    import io
+    from monte_carlo_portfolio_amd import ingest_np
+    e = G["monthly_seed12345"]
+    files = []
+    for f in G["files"]:
+        b = io.BytesIO(open(os.path.join(HERE, "golden", "data", f), "rb").read())
+        b.name = f
+        files.append(b)
+    names, days, P, R = ingest_np.load_returns(files, resample_rule="M", compat=True)
+    assert names == e["asset_names"] and np.array_equal(R, A["monthly_seed12345__returns_df"])
+    Rm, mean, cov = sweep.sweep_inputs(R, e["annual_factor"])
+    assert [float(v) for v in mean] == [hx(v) for v in e["mean_returns"]]
+    assert np.array_equal(cov, np.array([[hx(v) for v in row] for row in e["cov_matrix"]]))
+    res = sweep.run_all_methods(R, user_rf=e["user_rf"], annual_factor=e["annual_factor"], seed=12345)
+    for m, want in e["methods"].items():
+        assert res[m]["opt_idx"] == want["opt_idx"], m
+        np.testing.assert_allclose(res[m]["dollar_vals"], [hx(v) for v in want["dollar_vals"]], rtol=1e-15)

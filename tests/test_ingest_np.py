@@ -1,0 +1,133 @@
+"""the CSV -> returns matrix -> (mu, Sigma) path WITHOUT pandas (monte_carlo_portfolio_amd/ingest_np.py)
+against (a) the goldens produced by running the reference (G1-G3, tests/golden/make_goldens.py) and (b) the pandas twin
+(ingest.py) on every CSV the reference ships.  Bit for bit: the arithmetic of the pandas routines is restated."""
+import datetime
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from monte_carlo_portfolio_amd import ingest_np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(HERE, "golden", "data")
+F = json.load(open(os.path.join(HERE, "golden", "ref_functions.json")))
+G = json.load(open(os.path.join(HERE, "golden", "ref_script.json")))
+A = np.load(os.path.join(HERE, "golden", "ref_script_arrays.npz"))
+
+
+def hx(v):
+    return float.fromhex(v)
+
+
+def upload(name):
+    b = io.BytesIO(open(os.path.join(DATA, name), "rb").read())
+    b.name = name
+    return b
+
+
+def mk(text, name="x.csv"):
+    b = io.BytesIO(text.encode("utf-8"))
+    b.name = name
+    return b
+
+
+def iso(day):
+    return (datetime.date(1970, 1, 1) + datetime.timedelta(days=int(day))).isoformat()
+
+
+def test_the_module_does_not_import_pandas():
+    src = open(os.path.join(os.path.dirname(HERE), "monte_carlo_portfolio_amd", "ingest_np.py")).read()
+    assert "import pandas" not in src and "from pandas" not in src
+    import subprocess
+    code = "import sys; sys.path.insert(0, %r); import monte_carlo_portfolio_amd.ingest_np as m; assert 'pandas' not in sys.modules" % os.path.dirname(HERE)
+    # the package __init__ imports the pandas-based surface too; load the module file on its own
+    code = ("import sys, importlib.util; spec = importlib.util.spec_from_file_location('ingest_np', %r); m = importlib.util.module_from_spec(spec); "
+            "spec.loader.exec_module(m); assert 'pandas' not in sys.modules; print('ok')"
+            % os.path.join(os.path.dirname(HERE), "monte_carlo_portfolio_amd", "ingest_np.py"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr
+
+
+@pytest.mark.parametrize("name", sorted(F["G1_read_csv_file"]))
+def test_read_csv_file_matches_the_reference(name):
+    want = F["G1_read_csv_file"][name]
+    errors = []
+    got = ingest_np.read_csv_file(upload(name), compat=True, report=errors.append)
+    if want["result"] is None:
+        assert got is None and len(errors) == want["n_errors"] == 1            # Q1: thousands separators
+        return
+    d, p = got
+    assert errors == [] and len(d) == len(p) == want["rows"]
+    assert iso(d[0]) == want["first_date"] and iso(d[-1]) == want["last_date"]
+    assert iso(d.min()) == want["min_date"] and iso(d.max()) == want["max_date"]
+    assert p[0] == hx(want["first_price"]) and p[-1] == hx(want["last_price"])
+    assert p.min() == hx(want["min_price"]) and p.max() == hx(want["max_price"])
+
+
+@pytest.mark.parametrize("case", sorted(F["G1b_read_csv_synthetic"]))
+def test_header_sniffing_and_price_column_choice(case):
+    g = F["G1b_read_csv_synthetic"][case]
+    errors = []
+    got = ingest_np.read_csv_file(mk(g["text"]), compat=True, report=errors.append)
+    assert len(errors) == g["n_errors"]
+    if g["result"] is None:
+        assert got is None
+    else:
+        assert [iso(d) for d in got[0]] == g["result"]["dates"]
+        assert [float(v) for v in got[1]] == [hx(v) for v in g["result"]["prices"]]
+
+
+@pytest.mark.parametrize("compat", [True, False])
+def test_equal_to_the_pandas_twin_on_every_shipped_file(compat):
+    from monte_carlo_portfolio_amd import ingest
+    for name in sorted(os.listdir(DATA)):
+        a = ingest.read_csv_file(upload(name), compat=compat, report=lambda m: None)
+        b = ingest_np.read_csv_file(upload(name), compat=compat, report=lambda m: None)
+        assert (a is None) == (b is None), name
+        if a is not None:
+            assert np.array_equal(a["Date"].values.astype("datetime64[D]").astype(np.int64), b[0]), name
+            assert np.array_equal(a["Price"].values.view(np.uint64), b[1].view(np.uint64)), name
+
+
+@pytest.mark.parametrize("key,rule", [("monthly_seed12345", "M"), ("weekly_seed12345", "W")])
+def test_alignment_resampling_returns_mean_cov_match_the_reference_run(key, rule):
+    e = G[key]
+    names, days, P, R = ingest_np.load_returns([upload(f) for f in G["files"]], resample_rule=rule, compat=True)
+    assert names == e["asset_names"]
+    assert [iso(d) for d in days] == e["resampled_index"]
+    assert np.array_equal(P, A[f"{key}__resampled_prices"])
+    assert np.array_equal(R, A[f"{key}__returns_df"]) and list(R.shape) == e["returns_shape"]
+    mean, cov = ingest_np.sweep_inputs(R, ingest_np.ANNUAL_FACTOR[rule])
+    assert [float(v) for v in mean] == [hx(v) for v in e["mean_returns"]]               # DataFrame.mean() * annual_factor
+    assert np.array_equal(cov, np.array([[hx(v) for v in row] for row in e["cov_matrix"]]))   # DataFrame.cov() * annual_factor
+
+
+@pytest.mark.parametrize("rule", ["M", "Q", "W", "D"])
+def test_resampling_rules_equal_pandas_on_the_config0_files(rule):
+    from monte_carlo_portfolio_amd import ingest
+    files = ("Bitcoin Historical Data.csv", "Ethereum Historical Data.csv", "XAU_USD Historical Data.csv", "Solana Historical Data.csv")
+    names, prices, res = ingest.load_prices([upload(f) for f in files], resample_rule=rule, report=lambda m: None)
+    n2, days, P, R = ingest_np.load_returns([upload(f) for f in files], resample_rule=rule, report=lambda m: None)
+    assert names == n2 and [str(d.date()) for d in res.index] == [iso(d) for d in days]
+    assert np.array_equal(res.values, P)
+    assert np.array_equal(ingest.returns_matrix(res).values, R)
+    if R.shape[0] > 1:
+        rets = ingest.returns_matrix(res)
+        mean, cov = ingest_np.sweep_inputs(R, 1)
+        assert np.array_equal(rets.mean().values, mean) and np.array_equal(rets.cov().values, cov)
+
+
+def test_converter_matches_pandas_on_random_decimals():
+    import pandas as pd
+    rng = np.random.default_rng(0)
+    txt = [f"{rng.integers(0, 10 ** rng.integers(1, 12)) / 10 ** k:.{k}f}" for k in rng.integers(0, 9, 5000)]
+    txt += ["1e5", "2.5E-3", "-0.001", "+7.", "0.1234567890123456789", "1e22", "1e23", "9007199254740993", "0.30000000000000004"]
+    want = pd.read_csv(io.StringIO("x\n" + "\n".join(txt)), dtype=float)["x"].values
+    got = np.array([ingest_np.precise_xstrtod(t) for t in txt], float)
+    assert np.array_equal(want.view(np.uint64), got.view(np.uint64))
+    for bad in ("86,493.0", "abc", "", "1.2.3", "12 34", "--1"):
+        assert ingest_np.precise_xstrtod(bad) is None

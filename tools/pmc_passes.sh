@@ -11,7 +11,9 @@ for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_WAVE_CYCLES SQ_B
          "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INST_CYCLES_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD" \
          "GRBM_GUI_ACTIVE GRBM_COUNT" \
          "WRITE_SIZE" \
-         "FETCH_SIZE"; do
+         "FETCH_SIZE" \
+         "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT" \
+         "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pass$i -- python3 $R/tools/profile_paths.py "$@" > $R/$OUT/pass$i.log 2>&1 || echo "pass $i failed"
 done
