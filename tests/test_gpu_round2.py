@@ -58,7 +58,7 @@ def stats_of_values(values, alpha=0.95, v0=1.0, compounding="simple", rf=0.0):
 
 @pytest.mark.parametrize("case", ["ties_everywhere", "two_values", "quantised", "negative", "wide_range", "hi_ties", "one", "two",
                                   "sorted_desc", "big", "collapse_run"])
-@pytest.mark.parametrize("alpha", [0.95, 0.5, 0.999])
+@pytest.mark.parametrize("alpha", [0.95, 0.5, 0.999, 0.01, 1e-9])
 def test_statistics_pipeline_on_adversarial_values(gpu_ctx, case, alpha):
     import zlib
     rng = np.random.default_rng(zlib.crc32(case.encode()))
