@@ -282,7 +282,7 @@ def main():
     w = synthetic.equal_weights(N_ASSETS)
     mu32, L, W32 = prepare_inputs(mu, cov, w)
     eng = PathEngine(mu32, L, W32, N_STEPS, PATHS_PER_GPU, group=group, world_size=world, rank=rank,
-                     native_math=args.native_math)
+                     native_math=args.native_math, n_buffers=int(os.environ.get("MCP_BENCH_NBUF", "0")) or None)
 
     def sync():
         torch.cuda.synchronize()          # all three pipeline streams drained before the cross-rank barrier is issued
