@@ -266,6 +266,74 @@ def test_config4_ten_thousand_portfolios(gpu_ctx):
     assert np.all(np.abs(st["mean"] - ana) < 5 * st["std"] / np.sqrt(P))
 
 
+def test_config4_full_size_one_million_paths(gpu_ctx):
+    """BASELINE configs[4] at its own size on one GPU: 10,000 portfolios x 10^6 paths x 252 steps (0.75 s; 40 GB of
+    terminal values produced and reduced in 5 tiles of 2,048 portfolios, never resident).  Every count exact, the whole
+    field against the analytic mean, and the max-Sharpe portfolio's record against the oracle on all 10^6 paths."""
+    N, T, P, K = 16, 252, 1_000_000, 10_000
+    mu, cov = synthetic.synthetic_market(N)
+    W = synthetic.dirichlet_weights(N, K)
+    ctx = Context(0, terminal_budget=8 << 30)
+    try:
+        st = simulate_paths(mu, cov, W, n_steps=T, n_paths=P, seed=SEED, as_array=True, context=ctx)
+    finally:
+        ctx.close()
+    assert st.shape == (K,) and np.all(st["n"] == P) and np.all(st["n_tail"] >= 50_000) and np.all(st["n_tail"] <= 50_003)
+    mu32, L, W32 = prepare_inputs(mu, cov, W)
+    ana = (1.0 + W32.astype(np.float64) @ mu32.astype(np.float64)) ** T - 1.0
+    assert np.all(np.abs(st["mean"] - ana) < 5 * st["std"] / np.sqrt(P))
+    best = int(np.argmax(st["sharpe"]))
+    ref = mc_oracle.simulate(mu32, L, W32[best:best + 1], T, P, SEED)
+    check_against_reference({n: st[n][best] for n in st.dtype.names}, ref[0])
+
+
+def test_config2_hundred_million_paths_in_eight_shards(gpu_ctx):
+    """BASELINE configs[2] at its own size: 16 assets, 10^8 paths, 252 steps.  On this one-GPU box the eight 12.5 M-path
+    shards are eight logical shards of one device exchanging histograms and records inside the library exactly as eight
+    GPUs do over RCCL; the result must equal the single-shard run of all 10^8 paths: counts and order statistics exactly,
+    fp64 sums up to association, and both the analytic mean."""
+    N, T, P = 16, 252, 100_000_000
+    mu, cov = synthetic.synthetic_market(N)
+    w = synthetic.equal_weights(N)
+    one = simulate_paths(mu, cov, w, n_steps=T, n_paths=P, seed=SEED)
+    ctx = Context([0] * 8)
+    try:
+        eight = simulate_paths(mu, cov, w, n_steps=T, n_paths=P, seed=SEED, devices=[0] * 8, shard="paths", context=ctx)
+    finally:
+        ctx.close()
+    lo, hi, _ = _ffi.percentile_rank(P, 0.95)
+    assert one["n"] == eight["n"] == P and lo + 1 <= one["n_tail"] == eight["n_tail"] <= lo + 64     # ties at the quantile count too
+    for key in ("var", "x_lo", "x_hi", "min", "max"):
+        assert one[key] == eight[key], key
+    for key in ("mean", "std", "sharpe", "cvar", "sum_tail"):
+        assert eight[key] == pytest.approx(one[key], rel=1e-13), key
+    mu32, L, W32 = prepare_inputs(mu, cov, w)
+    ana = (1.0 + float(W32[0].astype(np.float64) @ mu32.astype(np.float64))) ** T - 1.0
+    assert abs(one["mean"] - ana) < 5 * one["std"] / np.sqrt(P)
+    assert one["x_lo"] <= one["var"] <= one["x_hi"] and one["cvar"] < one["var"]
+
+
+def test_config3_ten_million_paths_64_assets_1260_steps(gpu_ctx):
+    """BASELINE configs[3] at its own size (64 assets, 10^7 paths, 1,260 steps; 0.9 s): the first 1,024 paths bit-exact
+    against the oracle, the rest through counts, the analytic mean and the float64 drift bound of SPEC.md section 6."""
+    N, T, P = 64, 1260, 10_000_000
+    mu, cov = synthetic.synthetic_market(N)
+    w = synthetic.equal_weights(N)
+    r = simulate_paths(mu, cov, w, n_steps=T, n_paths=P, seed=SEED, store=True)
+    mu32, L, W32 = prepare_inputs(mu, cov, w)
+    ref = mc_oracle.simulate(mu32, L, W32, T, 1024, SEED)
+    assert np.array_equal(r["terminal"][:1024].view(np.uint32), ref[0].view(np.uint32))
+    r64 = mc_oracle.simulate_f64(mu32, L, W32, T, 1024, SEED)[0]
+    rel = r["terminal"][:1024].astype(np.float64) / r64 - 1.0
+    assert np.sqrt(np.mean(rel ** 2)) < 2 * np.sqrt(T) * 6e-8
+    lo, hi, _ = _ffi.percentile_rank(P, 0.95)
+    x = r["terminal"].astype(np.float64) - 1.0
+    assert r["var"] == np.percentile(x, (1 - 0.95) * 100)
+    assert r["n"] == P and r["n_tail"] == int((x <= r["var"]).sum()) >= lo + 1        # 10^7 binary32 values: ties at the quantile
+    ana = (1.0 + float(W32[0].astype(np.float64) @ mu32.astype(np.float64))) ** T - 1.0
+    assert abs(r["mean"] - ana) < 5 * r["std"] / np.sqrt(P)
+
+
 # ---------------------------------------------------------------- fp32 kernel against the float64 evaluation of the spec
 def test_gpu_statistics_match_float64_evaluation_at_one_million_paths(gpu_ctx):
     """north_star: Sharpe / VaR within 1e-6 of the NumPy (float64) reference on identical seeds.  The float64 oracle
