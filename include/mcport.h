@@ -101,8 +101,10 @@ const char *mcp_last_error(void);
 int mcp_ctx_create(int device, mcp_ctx **out);
 /* one context over `ndev` devices, one stream per device, the path range (or, with
  * MCP_FLAG_SHARD_PORTFOLIOS, the weight matrix) sharded over them.  Distinct devices exchange through RCCL
- * (ncclCommInitAll; librccl is loaded at run time, MCP_E_COMM if that fails); a device listed more than once holds
- * several logical shards that exchange through a kernel (what a one-GPU box can exercise).  ndev = 1 is
+ * (ncclCommInitAll; librccl is loaded at run time).  If librccl cannot be loaded or initialised -- or MCP_EXCHANGE=p2p is
+ * set -- and the first device has peer access to the others (at most 8 devices), the exchange runs as a kernel of the
+ * first device over peer access instead; MCP_E_COMM if neither is possible.  A device listed more than once holds
+ * several logical shards that exchange through that same kernel (what a one-GPU box can exercise).  ndev = 1 is
  * mcp_ctx_create.  Results equal the one-device results: order statistics, counts and argmax exactly, fp64 sums up to
  * association. */
 int mcp_ctx_create_multi(const int *devices, int ndev, mcp_ctx **out);
