@@ -160,6 +160,42 @@ def test_same_device_shards_equal_one_device(gpu_ctx, devices, P, K):
         check_against_reference({n: many[0][n][k] for n in many[0].dtype.names}, ref[k], rf=0.002)
 
 
+def test_random_shard_tile_configurations_equal_one_device(gpu_ctx):
+    """Fuzz over the host-level splitting logic: random shard counts (1..8 logical shards), path / portfolio sharding,
+    terminal budgets that force portfolio tiling, ragged K, N, T, P, both compounding modes -- every combination must give
+    the one-device, untiled records: counts and order statistics exactly, fp64 sums to 1e-13."""
+    rng = np.random.default_rng(2024)
+    plain = Context(0)
+    try:
+        for it in range(24):
+            N = int(rng.choice([1, 3, 4, 7, 16, 16, 21, 64]))
+            K = int(rng.choice([1, 1, 2, 9, 17, 40, 385, 700, 1300]))
+            T = int(rng.integers(1, 14))
+            P = int(rng.choice([1, 5, 63, 64, 65, 257, 1000, 4097, 20_000]))
+            S = int(rng.integers(1, 9))
+            comp = "log" if rng.random() < 0.3 else "simple"
+            shard = "portfolios" if (K >= 2 * S and rng.random() < 0.5) else "paths"
+            budget = int(rng.choice([8 << 30, max(4096, 4 * P * 600), max(4096, 4 * P * 3)]))
+            mu, cov = synthetic.synthetic_market(N)
+            W = synthetic.equal_weights(N) if K == 1 else synthetic.dirichlet_weights(N, K)
+            kw = dict(n_steps=T, n_paths=P, seed=1000 + it, compounding=comp, rf=0.001, alpha=float(rng.choice([0.95, 0.9, 0.5])),
+                      as_array=True, store=True, path_begin=int(rng.choice([0, 12345, (1 << 32) - 7])))
+            want = simulate_paths(mu, cov, W, context=plain, **kw)
+            ctx = Context([0] * S, terminal_budget=budget)
+            try:
+                got = simulate_paths(mu, cov, W, context=ctx, devices=[0] * S, shard=shard, **kw)
+            finally:
+                ctx.close()
+            tag = (it, N, K, T, P, S, comp, shard, budget)
+            assert np.array_equal(want[1].view(np.uint32), got[1].view(np.uint32)), tag
+            for key in ("n", "n_tail", "var", "x_lo", "x_hi", "min", "max"):
+                assert np.array_equal(want[0][key], got[0][key], equal_nan=True), (key, tag)
+            for key in ("mean", "std", "sharpe", "cvar", "sum_tail"):
+                np.testing.assert_allclose(got[0][key], want[0][key], rtol=1e-13, atol=1e-15, err_msg=str((key, tag)))
+    finally:
+        plain.close()
+
+
 def test_portfolio_sharding_inside_the_library(gpu_ctx):
     mu, cov = synthetic.synthetic_market(16)
     W = synthetic.dirichlet_weights(16, 1100)
