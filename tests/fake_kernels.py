@@ -2,8 +2,8 @@
 buffer layouts, computed on CPU torch tensors with NumPy and the C oracle.
 
 TEST INFRASTRUCTURE ONLY.  It exists so the multi-rank choreography of PathEngine.step (shard
-offsets, moment merge, histogram all-reduce between select passes, tail all-reduce) runs on CPU with
-world_size 2 over gloo.  The product never imports this module.
+offsets, histogram all-reduce between the select passes, all-gather of the records, rank-ordered merge)
+runs on CPU with world_size 2 over gloo.  The product never imports this module.
 """
 import ctypes
 
