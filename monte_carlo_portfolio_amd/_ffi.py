@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmcport.so")
+LIB_PATH = os.environ.get("MCP_LIB_PATH") or os.path.join(_PKG, "libmcport.so")     # MCP_LIB_PATH: a lab build (tools/kernel_lab.py)
 CSRC = os.path.join(_PKG, "csrc")
 
 MCP_ABI_VERSION = 2

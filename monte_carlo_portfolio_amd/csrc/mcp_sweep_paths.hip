@@ -187,7 +187,9 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
         s_z[3 * NB + q][lane] = z3;
       }
     }
+#ifndef MCP_EXP_NOBARRIER     // experiment only (wrong results): what the two barriers per step cost
     __syncthreads();
+#endif
     // phase B: this wave's row pairs of r = mu + L z
 #pragma unroll
     for (int m0 = 0; m0 < N4 / 2; m0 += 4) {
@@ -207,7 +209,9 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
         }
       }
     }
+#ifndef MCP_EXP_NOBARRIER
     __syncthreads();
+#endif
     // phase C: rho = W . r on the matrix cores, then compounding
     float b[2][KS];
 #pragma unroll
