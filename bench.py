@@ -176,6 +176,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--native-math", action="store_true", help="normals by hardware log/sqrt/sin/cos Box-Muller (not the spec's values)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true",
+                    help="one stream, batches back to back without overlap (for profiling: every mc_paths_kernel row of a "
+                         "--kernel-trace --stats summary is then a serial launch, comparable with roofline.kernel_ms)")
     ap.add_argument("--spawn", action="store_true", help="go through the rank-spawning parent also for --gpus 1")
     ap.add_argument("--backend", default=os.environ.get("MCP_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo-fake"],
                     help="gloo-fake: CPU rehearsal of the launcher and the rank choreography (tests/fake_kernels.py over gloo); "
@@ -282,7 +285,8 @@ def main():
     w = synthetic.equal_weights(N_ASSETS)
     mu32, L, W32 = prepare_inputs(mu, cov, w)
     eng = PathEngine(mu32, L, W32, N_STEPS, PATHS_PER_GPU, group=group, world_size=world, rank=rank,
-                     native_math=args.native_math, n_buffers=int(os.environ.get("MCP_BENCH_NBUF", "0")) or None)
+                     native_math=args.native_math, n_buffers=int(os.environ.get("MCP_BENCH_NBUF", "0")) or None,
+                     pipeline=not args.serial)
 
     def sync():
         torch.cuda.synchronize()          # all three pipeline streams drained before the cross-rank barrier is issued
@@ -415,7 +419,8 @@ def main():
                        "n_assets": N_ASSETS, "n_steps": N_STEPS, "paths_per_gpu": PATHS_PER_GPU,
                        "global_paths": PATHS_PER_GPU * world, "parallelism": f"path-sharded x{world}",
                        "math": "native" if args.native_math else "exact",
-                       "pipeline": "double-buffered batches: path kernel i+1 overlaps statistics + collectives of batch i"},
+                       "pipeline": ("serial: one stream, no overlap (profiling mode)" if args.serial else
+                                    "double-buffered batches: path kernel i+1 overlaps statistics + collectives of batch i")},
             "stats": {"mean": float(stats["mean"]), "std": float(stats["std"]), "sharpe": float(stats["sharpe"]),
                       "var95": float(stats["var"]), "cvar95": float(stats["cvar"]), "n": int(stats["n"]),
                       "n_tail": int(stats["n_tail"])},
