@@ -24,6 +24,9 @@ constexpr uint32_t PHILOX_W1 = 0xBB67AE85u;
 #ifndef MCP_EXP_VMUL
 #define MCP_EXP_VMUL 0
 #endif
+#ifndef MCP_EXP_NORMALS4
+#define MCP_EXP_NORMALS4 1
+#endif
 
 // a ^ b ^ c in one VALU instruction (v_bitop3_b32, truth table 0x96).
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
@@ -138,10 +141,35 @@ __device__ __forceinline__ void block_normals(const uint32_t (&x)[4], const floa
     box_muller_native(x[0], x[1], z0, z1);
     box_muller_native(x[2], x[3], z2, z3);
   } else {
+#if MCP_EXP_NORMALS4
+    // the same four transforms with the four table reads issued together, ahead of everything that depends on them
+    // (one s_waitcnt per block instead of one per normal), and the four Horner chains interleaved
+    uint32_t b[4];
+    float4 c[4];
+    float dc[4], a[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) b[i] = __float_as_uint(fma32((float)(x[i] & 0x7fffffffu), 0x1p-125f, 0x1p-126f));
+#pragma unroll
+    for (int i = 0; i < 4; i++) c[i] = *(const float4*)((const char*)tab + ((b[i] >> 14) & 0x0003fff0u));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) dc[i] = __uint_as_float((b[i] & k.m18) | 0x3f800000u) - 0x1.04p+0f;   // (as v_pk_add_f32 pairs: +4 %)
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = fma32(c[i].w, dc[i], c[i].z);
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = fma32(a[i], dc[i], c[i].y);
+#pragma unroll
+    for (int i = 0; i < 4; i++) a[i] = fma32(a[i], dc[i], c[i].x);
+    z0 = __uint_as_float(bitselect(k.m31, __float_as_uint(a[0]), x[0]));
+    z1 = __uint_as_float(bitselect(k.m31, __float_as_uint(a[1]), x[1]));
+    z2 = __uint_as_float(bitselect(k.m31, __float_as_uint(a[2]), x[2]));
+    z3 = __uint_as_float(bitselect(k.m31, __float_as_uint(a[3]), x[3]));
+#else
     z0 = normal_icdf(x[0], tab, k);
     z1 = normal_icdf(x[1], tab, k);
     z2 = normal_icdf(x[2], tab, k);
     z3 = normal_icdf(x[3], tab, k);
+#endif
   }
 }
 

@@ -23,8 +23,8 @@
 #ifndef MCP_EXP_VKEYS
 #define MCP_EXP_VKEYS 1
 #endif
-#ifndef MCP_EXP_LDSPAR      // 1: drift from LDS; 2: drift and (one portfolio) weights from LDS
-#define MCP_EXP_LDSPAR 0
+#ifndef MCP_EXP_LDSPAR      // 1: drift from LDS (default); 2: drift and (one portfolio) weights from LDS; 0: both from SGPRs
+#define MCP_EXP_LDSPAR 1
 #endif
 
 namespace mcp {
