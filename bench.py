@@ -465,7 +465,17 @@ def main():
             np.where(series <= v_np, series, 0.0).sum(axis=0) / (series <= v_np).sum(axis=0)
             (Wm @ mean_h - 0.03) / np.sqrt(np.einsum("pi,ij,pj->p", Wm, cov_h, Wm))
             t_np = time.perf_counter() - t0
+            Rs = np.random.default_rng(1).normal(0.01, 0.15, (13, 3))          # the shape of the reference's own run: 13 monthly rows x 3 assets
+            sweep.run_all_methods(Rs, user_rf=3.0, annual_factor=12, seed=0)
+            t0 = time.perf_counter()
+            for i in range(5):
+                sweep.run_all_methods(Rs, user_rf=3.0, annual_factor=12, seed=i)
+            t_tab2 = (time.perf_counter() - t0) / 5
             out["historical_sweep"] = {
+                "tab2_loop": {"workload": "the whole loop of app.py:682-722: 5 methods, 4 x 2,500 Dirichlet portfolios + equal weights, 13 x 3 returns; "
+                                          "weights from NumPy's legacy stream exactly as the reference draws them (block-drawn), scoring on the GPU",
+                              "seconds": t_tab2, "portfolios_per_s": 10_001 / t_tab2,
+                              "reference_portfolios_per_s": 1850, "reference_note": "app.py:699-717 as written at 13 x 3, 1 core, survey container (SURVEY.md section 6)"},
                 "workload": "10,000 Dirichlet portfolios x 252 rows x 16 assets, loop body app.py:708-713",
                 "gpu_portfolios_per_s_incl_pcie": 10_000 / t_gpu, "numpy_vectorised_portfolios_per_s": 10_000 / t_np,
                 "reference_loop_portfolios_per_s": 1940, "reference_loop_note": "app.py:699-717 as written, 1 core, survey container (BASELINE.md section 2)",
