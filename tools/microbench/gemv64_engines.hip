@@ -16,6 +16,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -51,6 +52,42 @@ __global__ void __launch_bounds__(256) gemv_valu(const float* __restrict__ packe
       }
       rho = __builtin_fmaf(Wk[2 * m], acc.x, rho);
       rho = __builtin_fmaf(Wk[2 * m + 1], acc.y, rho);
+    }
+    V = __builtin_fmaf(V, rho, V);
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = V;
+}
+
+// ---- VALU, quad rows: four rows per SGPR quad (L[4g..4g+3][j]), two independent v_pk_fma_f32 chains per column ----------
+// Same FMAs plus 2 packed zero-FMAs per quad (rows 4g, 4g+1 run to column 4g+3); the two accumulators of a column are
+// independent, so consecutive instructions never depend on each other.
+__global__ void __launch_bounds__(256) gemv_valu_quad(const float* __restrict__ packed, const float* __restrict__ quad, int T, float* __restrict__ out) {
+  typedef const __attribute__((address_space(4))) float* cfloat_p;
+  cfloat_p mu = (cfloat_p)packed;
+  cfloat_p Lq = (cfloat_p)quad;
+  cfloat_p Wk = mu + N + N * (N / 2 + 1);
+  float V = 1.0f;
+  const uint32_t lane_seed = blockIdx.x * 256 + threadIdx.x;
+  for (int t = 0; t < T; t++) {
+    asm volatile("" : "+s"(mu), "+s"(Lq), "+s"(Wk));
+    float z[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) z[j] = fake_z(lane_seed + t, j);
+    float rho = 0.0f;
+#pragma unroll
+    for (int g = 0; g < N / 4; g++) {
+      f32x2 a0 = {mu[4 * g], mu[4 * g + 1]}, a1 = {mu[4 * g + 2], mu[4 * g + 3]};
+      const int base = 8 * g * (g + 1);                      // 4 * sum_{h<g} (4h + 4)
+#pragma unroll
+      for (int j = 0; j <= 4 * g + 3; j++) {
+        const f32x2 l0 = {Lq[base + 4 * j], Lq[base + 4 * j + 1]}, l1 = {Lq[base + 4 * j + 2], Lq[base + 4 * j + 3]};
+        a0 = __builtin_elementwise_fma(l0, (f32x2){z[j], z[j]}, a0);
+        a1 = __builtin_elementwise_fma(l1, (f32x2){z[j], z[j]}, a1);
+      }
+      rho = __builtin_fmaf(Wk[4 * g], a0.x, rho);
+      rho = __builtin_fmaf(Wk[4 * g + 1], a0.y, rho);
+      rho = __builtin_fmaf(Wk[4 * g + 2], a1.x, rho);
+      rho = __builtin_fmaf(Wk[4 * g + 3], a1.y, rho);
     }
     V = __builtin_fmaf(V, rho, V);
   }
@@ -123,7 +160,13 @@ int main(int argc, char** argv) {
   for (int i = 0; i < N; i++) packed[i] = mu[i];
   for (int i = 0; i < N; i++) for (int j = 0; j <= i; j++) packed[N + 2 * (i / 2) * (i / 2 + 1) + 2 * j + (i & 1)] = Ld[i * N + j];
   for (int i = 0; i < N; i++) packed[N + N * (N / 2 + 1) + i] = w[i];
-  float *d_packed, *d_L, *d_mu, *d_w, *d_out;
+  std::vector<float> quad;
+  for (int g = 0; g < N / 4; g++)
+    for (int j = 0; j <= 4 * g + 3; j++)
+      for (int h = 0; h < 4; h++) quad.push_back(j <= 4 * g + h ? Ld[(4 * g + h) * N + j] : 0.0f);
+  float *d_packed, *d_L, *d_mu, *d_w, *d_out, *d_quad;
+  CHECK(hipMalloc(&d_quad, quad.size() * 4));
+  CHECK(hipMemcpy(d_quad, quad.data(), quad.size() * 4, hipMemcpyHostToDevice));
   const int blocks_per_cu = 2, grid = cus * blocks_per_cu * 4;   // several rounds of workgroups
   CHECK(hipMalloc(&d_packed, packed.size() * 4)); CHECK(hipMalloc(&d_L, Ld.size() * 4)); CHECK(hipMalloc(&d_mu, N * 4));
   CHECK(hipMalloc(&d_w, N * 4)); CHECK(hipMalloc(&d_out, (size_t)grid * 256 * 4));
@@ -134,25 +177,30 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
   std::vector<float> ref((size_t)grid * 256), got((size_t)grid * 256);
-  for (int which = 0; which < 2; which++) {
+  std::vector<float> got2((size_t)grid * 256);
+  for (int which = 0; which < 3; which++) {
     float best = 1e30f;
     for (int rep = 0; rep < 5; rep++) {
       CHECK(hipEventRecord(e0));
       if (which == 0) gemv_valu<<<grid, 256>>>(d_packed, T, d_out);
-      else gemv_mfma<<<grid, 256>>>(d_L, d_mu, d_w, T, d_out);
+      else if (which == 1) gemv_mfma<<<grid, 256>>>(d_L, d_mu, d_w, T, d_out);
+      else gemv_valu_quad<<<grid, 256>>>(d_packed, d_quad, T, d_out);
       CHECK(hipEventRecord(e1));
       CHECK(hipEventSynchronize(e1));
       float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
       if (ms < best) best = ms;
     }
-    CHECK(hipMemcpy(which == 0 ? ref.data() : got.data(), d_out, (size_t)grid * 256 * 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(which == 0 ? ref.data() : (which == 1 ? got.data() : got2.data()), d_out, (size_t)grid * 256 * 4, hipMemcpyDeviceToHost));
     const double wave_steps = (double)grid * 4 * T;
     const double cyc = best * 1e-3 * 2.4e9 * (cus * 4) / wave_steps;     // SIMD-cycles at the nominal 2.4 GHz per wave-step
     printf("%-5s  %8.3f ms for %d workgroups x %d steps -> %7.0f SIMD-cycles@2.4GHz per wave-step (64 paths x 1 step), %.2f us per wave-step-round\n",
-           which == 0 ? "VALU" : "MFMA", best, grid, T, cyc, best * 1e3 / T);
+           which == 0 ? "VALU" : (which == 1 ? "MFMA" : "VALU4"), best, grid, T, cyc, best * 1e3 / T);
   }
   double maxrel = 0;
   for (size_t i = 0; i < ref.size(); i++) { const double r = fabs((double)got[i] / (double)ref[i] - 1.0); if (r > maxrel) maxrel = r; }
   printf("max relative difference of the final values MFMA vs VALU: %.2e (different summation order inside a 16x16x4 tile)\n", maxrel);
+  size_t diff = 0;
+  for (size_t i = 0; i < ref.size(); i++) diff += memcmp(&ref[i], &got2[i], 4) != 0;
+  printf("VALU4 (quad rows) vs VALU (row pairs): %zu of %zu values differ\n", diff, ref.size());
   return 0;
 }
