@@ -180,9 +180,10 @@ def main():
                     help="one stream, batches back to back without overlap (for profiling: every mc_paths_kernel row of a "
                          "--kernel-trace --stats summary is then a serial launch, comparable with roofline.kernel_ms)")
     ap.add_argument("--spawn", action="store_true", help="go through the rank-spawning parent also for --gpus 1")
-    ap.add_argument("--backend", default=os.environ.get("MCP_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo-fake"],
+    ap.add_argument("--backend", default=os.environ.get("MCP_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo", "gloo-fake"],
                     help="gloo-fake: CPU rehearsal of the launcher and the rank choreography (tests/fake_kernels.py over gloo); "
-                         "prints a line marked rehearsal, never a measurement")
+                         "gloo: the real kernels with the collectives over gloo, ranks sharing the visible GPUs round-robin "
+                         "(rehearsal of N > 1 on a one-GPU box).  Both print a line marked rehearsal, never a measurement")
     ap.add_argument("--sweep", action="store_true",
                     help="side benchmark, NOT the BASELINE metric: configs[4] shape (10,000 Dirichlet portfolios, 16 assets, "
                          "252 steps, --sweep-paths paths), portfolio-sharded over the ranks, MFMA kernel")
@@ -212,10 +213,16 @@ def main():
         sys.exit(3)
     if args.backend == "gloo-fake":
         return rehearsal(args, world, rank)
+    rehearse = args.backend == "gloo"
+    if rehearse:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:     # under torch.distributed.run also with one rank (exercises RCCL)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         group = dist.group.WORLD
 
     from monte_carlo_portfolio_amd import synthetic
@@ -410,7 +417,8 @@ def main():
                     "frac": HBM_BYTES_PER_PATH * k_paths_s / 1e9 / HBM_PEAK_GBS},
         }
         out = {
-            "metric": "simulated paths/sec (16 assets x 252 steps) + VaR abs-err vs NumPy ref",
+            "metric": ("REHEARSAL (ranks share the GPU, collectives over gloo; not a measurement)" if rehearse else
+                       "simulated paths/sec (16 assets x 252 steps) + VaR abs-err vs NumPy ref"),
             "value": value, "unit": "paths/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -62,3 +62,16 @@ def test_gpu_bench_through_the_spawning_parent():
     assert out["stats"]["n"] == 1_000_000 and out["stats"]["n_tail"] == 50_000
     rf = out["roofline"]
     assert rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_gpu_bench_two_ranks_share_the_gpu_over_gloo():
+    """N = 2 through bench.py itself on the one-GPU box: the parent spawns two ranks, both drive the real kernels on GPU 0,
+    the collectives (three histogram all-reduces, one record all-gather per step, the barrier and the MAX of the times) go
+    over gloo.  A rehearsal of the multi-rank code path, not a measurement -- the line says so."""
+    r = run_bench("--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--paths-per-gpu", "200000")
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = last_json(r.stdout)
+    assert out["metric"].startswith("REHEARSAL") and out["n_gpus"] == 2
+    assert out["stats"]["n"] == 400_000 and out["stats"]["n_tail"] == 20_000          # global statistics over both shards
+    assert out["config"]["global_paths"] == 400_000 and out["value"] > 1e6
