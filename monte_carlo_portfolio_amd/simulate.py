@@ -8,6 +8,7 @@ validates, factors Sigma (float64 Cholesky on the host, cast to fp32) and marsha
 """
 from __future__ import annotations
 
+import atexit
 import ctypes
 import threading
 
@@ -61,6 +62,21 @@ class Context:
             term.ctypes.data_as(ctypes.c_void_p) if store else None,
             stats.ctypes.data_as(ctypes.c_void_p)))
         return stats, term
+
+
+def _close_default_contexts() -> None:
+    """Interpreter exit: destroy the cached contexts (streams, device buffers, RCCL communicators) while the HIP runtime
+    and the library are still loaded."""
+    with _CTX_LOCK:
+        for ctx in list(_CTX.values()):
+            try:
+                ctx.close()
+            except Exception:
+                pass
+        _CTX.clear()
+
+
+atexit.register(_close_default_contexts)
 
 
 def default_context(device=0) -> Context:
