@@ -133,7 +133,9 @@ class PathEngine:
         if self.pipeline:
             # one path stream per buffer: the next batch's path kernel fills the CUs that the previous one's
             # last (partial) round of waves leaves idle
-            self.s_paths = [torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)]
+            import os
+            n_ps = max(1, min(int(os.environ.get("MCP_ENGINE_PATH_STREAMS", "2")), self.n_buf))
+            self.s_paths = [torch.cuda.Stream(self.device) for _ in range(n_ps)]
             self.s_stats = torch.cuda.Stream(self.device, priority=-1)   # small kernels: dispatch ahead of path blocks
             self.ev_paths = [torch.cuda.Event() for _ in range(self.n_buf)]
             self.ev_stats = [torch.cuda.Event() for _ in range(self.n_buf)]
@@ -184,7 +186,7 @@ class PathEngine:
             self._enqueue_stats(b)
         else:
             torch = self.torch
-            sp = self.s_paths[i % 2]
+            sp = self.s_paths[i % len(self.s_paths)]
             with torch.cuda.stream(sp):
                 sp.wait_event(self.ev_stats[i])                 # the pass that last used this buffer is done
                 self._enqueue_paths(b, seed, path_base)
