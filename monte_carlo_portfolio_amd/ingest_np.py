@@ -122,10 +122,8 @@ def _parse_dates(strings):
     """-> int64 days since 1970-01-01, NaT as the minimum int64.  The format is inferred from the first parsable row."""
     NAT = np.iinfo(np.int64).min
     fmt = None
-    for s in strings:
-        s = s.strip()
-        if not s:
-            continue
+    for s in strings:                                        # the first row that parses decides (a leading unparsable row makes
+        s = s.strip()                                        # pandas parse row by row; for one format per file the result is the same)
         for f in _DATE_FORMATS:
             try:
                 _dt.datetime.strptime(s, f)
@@ -133,7 +131,8 @@ def _parse_dates(strings):
                 break
             except ValueError:
                 continue
-        break
+        if fmt is not None:
+            break
     out = np.full(len(strings), NAT, np.int64)
     if fmt is None:
         return out
@@ -154,6 +153,9 @@ def read_csv_file(file, compat: bool = False, report=None):
         rows = [r for r in csv.reader(io.StringIO(_decode(file))) if r]
         if not rows:
             raise ValueError("empty file")
+        wide = next((i for i, r in enumerate(rows) if len(r) > len(rows[0])), None)
+        if wide is not None:                                  # pandas' tokenizer: the first line fixes the field count
+            raise ValueError(f"Error tokenizing data: expected {len(rows[0])} fields in line {wide + 1}, saw {len(rows[wide])}")
         # the reference takes line 0 as the header if it names a date column, else the first of lines 0..4 that does
         hdr = next((i for i in range(min(5, len(rows))) if "date" in [_norm(c) for c in rows[i]]), None)
         if hdr is None:
