@@ -133,58 +133,56 @@ def test_converter_matches_pandas_on_random_decimals():
         assert ingest_np.precise_xstrtod(bad) is None
 
 
-def test_fuzz_against_the_pandas_twin():
-    """300 random price files -- with / without BOM, quoted or not, thousands separators, two date formats, junk lines before
-    the header, missing and NA cells, unparsable dates, header variants and price-column choices, ragged lines -- through
-    both loaders in both modes: the same rejection decisions and the same (date, price) arrays, bit for bit."""
-    import datetime
-    import random
+
+def _fuzz_cases():
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import fuzz_csv
+    return fuzz_csv.cases()
+
+
+def _bio(text, bom):
+    b = io.BytesIO((("\ufeff" if bom else "") + text).encode("utf-8"))
+    b.name = "f.csv"
+    return b
+
+
+def test_fuzz_against_the_reference_itself():
+    """300 random price files (tests/golden/fuzz_csv.py: BOM, quotes, thousands separators, two date formats, junk lines before
+    the header, NA cells, unparsable dates, header variants, ragged lines) through BOTH loaders in compat mode against what the
+    REFERENCE's own read_csv_file returned for them (tests/golden/make_fuzz_goldens.py -> ref_fuzz_csv.json): the same 74
+    rejections, and for the rest the same dates and prices, bit for bit."""
+    import hashlib
     import warnings
     from monte_carlo_portfolio_amd import ingest
-
-    def mk2(text, bom):
-        b = io.BytesIO((("\ufeff" if bom else "") + text).encode("utf-8"))
-        b.name = "f.csv"
-        return b
-
-    rnd = random.Random(1)
-    d0 = datetime.date(2024, 1, 1)
-    n_none = n_ok = 0
+    gold = json.load(open(os.path.join(HERE, "golden", "ref_fuzz_csv.json")))
+    cases = _fuzz_cases()
+    assert len(cases) == gold["n"] == 300 and gold["none"] == 74
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for it in range(300):
-            n = rnd.randint(1, 30)
-            quoted, thousands = rnd.random() < 0.5, rnd.random() < 0.3
-            datefmt = rnd.choice(["%m/%d/%Y", "%Y-%m-%d"])
-            cols = rnd.choice([["Date", "Price", "Open"], ["date", "Close", "Vol."], ["Date", "Volume", "Adj Close", "Open"],
-                               ["Time", "Date", "Value"], [" Date ", "PRICE"]])
-            rows = []
-            for i in range(n):
-                d = d0 + datetime.timedelta(days=rnd.randint(0, 400))
-                row = []
-                for c in cols:
-                    if c.strip().lower() == "date":
-                        row.append(d.strftime(datefmt) if rnd.random() > 0.05 else rnd.choice(["", "n/a", "garbage"]))
-                    elif c.strip().lower() == "time":
-                        row.append("12:00")
-                    else:
-                        v = rnd.choice([rnd.uniform(0.001, 5), rnd.uniform(5, 999), rnd.uniform(1000, 99999)])
-                        cell = f"{v:,.{rnd.randint(0, 6)}f}" if thousands else f"{v:.{rnd.randint(0, 6)}f}"
-                        row.append(rnd.choice(["", "NA", "-", "null"]) if rnd.random() < 0.05 else cell)
-                rows.append(row)
-            pre = [["junk", "", ""]] * rnd.choice([0, 0, 0, 1, 2])
+        for (text, bom), want in zip(cases, gold["cases"]):
+            a = ingest.read_csv_file(_bio(text, bom), compat=True, report=lambda m: None)
+            b = ingest_np.read_csv_file(_bio(text, bom), compat=True, report=lambda m: None)
+            if want is None:
+                assert a is None and b is None, text[:200]
+                continue
+            assert a is not None and b is not None and len(a) == len(b[0]) == want["rows"], text[:200]
+            da = np.ascontiguousarray(a["Date"].values.astype("datetime64[D]").astype(np.int64))
+            pa = np.ascontiguousarray(a["Price"].values.astype(np.float64))
+            for days, price in ((da, pa), (np.ascontiguousarray(b[0]), np.ascontiguousarray(b[1]))):
+                assert hashlib.sha256(days.tobytes()).hexdigest()[:16] == want["dates"], text[:200]
+                assert hashlib.sha256(price.tobytes()).hexdigest()[:16] == want["prices"], text[:200]
 
-            def fmt(r):
-                return ",".join((f'"{x}"' if (quoted or "," in x) else x) for x in r)
-            text = "\n".join([fmt(r[:len(cols)]) for r in pre] + [fmt(cols)] + [fmt(r) for r in rows]) + "\n"
-            for compat in (True, False):
-                a = ingest.read_csv_file(mk2(text, it % 2 == 0), compat=compat, report=lambda m: None)
-                b = ingest_np.read_csv_file(mk2(text, it % 2 == 0), compat=compat, report=lambda m: None)
-                assert (a is None) == (b is None), (it, compat, text[:300])
-                if a is None:
-                    n_none += 1
-                    continue
-                n_ok += 1
-                assert np.array_equal(a["Date"].values.astype("datetime64[D]").astype(np.int64), b[0]), (it, compat)
-                assert np.array_equal(a["Price"].values.astype(np.float64).view(np.uint64), b[1].view(np.uint64)), (it, compat)
-    assert n_none > 20 and n_ok > 300          # the generator exercises both outcomes
+
+def test_fuzz_default_mode_equals_the_pandas_twin():
+    """The default (thousands-separator-parsing) mode has no reference counterpart: the two loaders must agree with each other."""
+    import warnings
+    from monte_carlo_portfolio_amd import ingest
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for text, bom in _fuzz_cases():
+            a = ingest.read_csv_file(_bio(text, bom), compat=False, report=lambda m: None)
+            b = ingest_np.read_csv_file(_bio(text, bom), compat=False, report=lambda m: None)
+            assert (a is None) == (b is None), text[:200]
+            if a is not None:
+                assert np.array_equal(a["Date"].values.astype("datetime64[D]").astype(np.int64), b[0])
+                assert np.array_equal(a["Price"].values.astype(np.float64).view(np.uint64), b[1].view(np.uint64))
