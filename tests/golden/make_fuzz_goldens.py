@@ -40,6 +40,40 @@ def main():
                             "prices": hashlib.sha256(np.ascontiguousarray(price).tobytes()).hexdigest()[:16]})
     json.dump({"n": len(out), "none": sum(o is None for o in out), "cases": out}, open(os.path.join(HERE, "ref_fuzz_csv.json"), "w"))
     print("wrote ref_fuzz_csv.json:", len(out), "cases,", sum(o is None for o in out), "rejected by the reference")
+
+    # the scalar metrics (app.py:231-263) and the options overlay / payoff functions (app.py:164-229) on random inputs
+    import fuzz_surface
+    import pandas as pd
+    fl = make_goldens.fl
+
+    def dig(a):
+        return hashlib.sha256(np.ascontiguousarray(np.asarray(a, np.float64)).tobytes()).hexdigest()[:16]
+    met = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for c in fuzz_surface.metric_cases():
+            r = pd.Series(c["returns"])
+            met.append({"sharpe": fl(ns["sharpe_ratio"](r, c["rf"], c["ann"])), "sortino": fl(ns["sortino_ratio"](r, c["rf"], c["ann"])),
+                        "vol": fl(ns["annual_volatility"](r, c["ann"])), "ret": fl(ns["annual_return"](r, c["ann"])),
+                        "mdd": fl(ns["max_drawdown"](r)), "var": fl(ns["var"](r, c["alpha"])), "cvar": fl(ns["cvar"](r, c["alpha"]))})
+        opt = []
+        for c in fuzz_surface.option_cases():
+            ser = ns["calc_options_series"](c["rows"], pd.Series(c["prices"]))
+            pay = ns["calculate_payoff"](c["rows"], c["spot"], c["purchase"], c["grid"])
+            be = ns["calculate_breakeven"](c["rows"], c["purchase"])
+            qty_asset = sum(q for t, k, p, q in c["rows"] if t == fuzz_surface.T_BUY) or 1.0
+            pl = ns["calculate_profit_loss_percent"](pay, c["purchase"], qty_asset)
+            opt.append({"series": dig(ser.values), "series_len": int(len(ser)), "payoff": dig(pay), "breakeven": None if be is None else fl(be),
+                        "pl": dig(pl)})
+    ast_ = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for c in fuzz_surface.asset_cases():
+            ser = pd.Series(c["prices"], index=pd.to_datetime(c["days"], unit="D"))
+            d = ns["calc_asset_stats"](ser, c["freq"], c["rf"])
+            ast_.append({k: (fl(v) if k != "returns" else dig(v.values)) for k, v in d.items()} | {"n_returns": int(len(d["returns"]))})
+    json.dump({"metrics": met, "options": opt, "assets": ast_}, open(os.path.join(HERE, "ref_fuzz_surface.json"), "w"))
+    print("wrote ref_fuzz_surface.json:", len(met), "metric cases,", len(opt), "option cases,", len(ast_), "asset-statistics cases")
     return 0
 
 

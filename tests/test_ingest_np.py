@@ -186,3 +186,37 @@ def test_fuzz_default_mode_equals_the_pandas_twin():
             if a is not None:
                 assert np.array_equal(a["Date"].values.astype("datetime64[D]").astype(np.int64), b[0])
                 assert np.array_equal(a["Price"].values.astype(np.float64).view(np.uint64), b[1].view(np.uint64))
+
+
+def test_fuzz_alignment_and_resampling_equal_the_pandas_pipeline():
+    """Random multi-asset date sets (gaps, partial overlap, descending order) through the inner join + last-of-period
+    resampling + pct_change of both pipelines, for M / Q / W / D: identical period labels, prices, returns, mean and cov."""
+    import pandas as pd
+    import warnings
+    from monte_carlo_portfolio_amd import ingest
+    rng = np.random.default_rng(5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it in range(60):
+            n_assets = int(rng.integers(1, 5))
+            base = np.arange(19000, 19000 + int(rng.integers(40, 500)))
+            series_np, frames = [], []
+            for a in range(n_assets):
+                keep = np.sort(rng.choice(base, size=int(len(base) * rng.uniform(0.6, 1.0)), replace=False))
+                price = 20 * np.cumprod(1 + rng.normal(0, 0.03, len(keep))) + 0.1
+                if rng.random() < 0.5:
+                    keep, price = keep[::-1].copy(), price[::-1].copy()
+                series_np.append((f"A{a}", (keep.astype(np.int64), price)))
+                frames.append((f"A{a}", pd.DataFrame({"Date": pd.to_datetime(keep, unit="D"), "Price": price})))
+            rule = ["M", "Q", "W", "D"][it % 4]
+            names, prices, res = ingest.align_prices(frames, rule)
+            n2, days, P = ingest_np.align_prices(series_np, rule)
+            assert names == n2 and [str(d.date()) for d in res.index] == [iso(d) for d in days], (it, rule)
+            assert np.array_equal(res.values, P)
+            R = ingest_np.returns_matrix(P)
+            rets = ingest.returns_matrix(res)
+            assert np.array_equal(rets.values, R)
+            if R.shape[0] > 2:
+                mean, cov = ingest_np.sweep_inputs(R, 12)
+                assert np.array_equal((rets.mean() * 12).values, mean)
+                assert np.array_equal(np.atleast_2d((rets.cov() * 12).values), cov)
