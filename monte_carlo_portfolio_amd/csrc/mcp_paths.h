@@ -38,6 +38,7 @@ struct PathArgs {
   const float4* __restrict__ tables;  // [ICDF_ENTRIES] inverse-CDF coefficient table (device copy of mcp_icdf_table.inc)
   uint64_t seed, path_begin, n_paths, stride;
   int32_t n_steps, n_portfolios, k_begin, compounding;
+  int32_t k_count;                    // sweep kernels: portfolios [k_begin, k_begin + k_count) belong to this launch
   float v0;
   uint32_t fold_offset;               // float index of [c, v_0 .. v_{N4-1}] (portfolio 0 folded through L, SPEC.md 4.1)
 };

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
   const uint64_t p = ((uint64_t)blockIdx.x * (PATH_BLOCK / 64) + wave) * 64 + lane;     // local path of this lane (draw)
   const uint64_t g = a.path_begin + p;
   const uint32_t plo = (uint32_t)g, phi = (uint32_t)(g >> 32);
-  const int k_base = blockIdx.y * 32 * MT;
+  const int k_base = a.k_begin + blockIdx.y * 32 * MT;
   constexpr bool logc = LOGC;      // compile-time: a run-time flag turns the compounding into fma + add + select
 
   float areg[MT][KS];
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
   const uint64_t p = (uint64_t)blockIdx.x * 64 + lane;             // all four waves: the same 64 paths
   const uint64_t g = a.path_begin + p;
   const uint32_t plo = (uint32_t)g, phi = (uint32_t)(g >> 32);
-  const int k_base = (blockIdx.y * 4 + wave) * 32 * MT;
+  const int k_base = a.k_begin + (blockIdx.y * 4 + wave) * 32 * MT;
   constexpr bool logc = LOGC;      // compile-time: a run-time flag turns the compounding into fma + add + select
 
   float areg[MT][KS];
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
 template <int NB>
 static hipError_t go_shared(bool native, const PathArgs& args, hipStream_t stream) {
   constexpr int MT = NB <= 4 ? 4 : 2;
-  const dim3 grid((unsigned)((args.n_paths + 63) / 64), (unsigned)((args.n_portfolios + 128 * MT - 1) / (128 * MT)));
+  const dim3 grid((unsigned)((args.n_paths + 63) / 64), (unsigned)((args.k_count + 128 * MT - 1) / (128 * MT)));
   const bool lg = args.compounding == MCP_COMPOUND_LOG;
   if (native) { if (lg) mc_sweep_shared_kernel<NB, MT, true, true><<<grid, PATH_BLOCK, 0, stream>>>(args); else mc_sweep_shared_kernel<NB, MT, true, false><<<grid, PATH_BLOCK, 0, stream>>>(args); }
   else { if (lg) mc_sweep_shared_kernel<NB, MT, false, true><<<grid, PATH_BLOCK, 0, stream>>>(args); else mc_sweep_shared_kernel<NB, MT, false, false><<<grid, PATH_BLOCK, 0, stream>>>(args); }
@@ -302,7 +302,7 @@ static hipError_t go_nb(int mt, bool native, const PathArgs& args, const dim3 gr
 
 hipError_t launch_sweep_paths(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream) {
   const unsigned gx = (unsigned)((args.n_paths + PATH_BLOCK - 1) / PATH_BLOCK);
-  const unsigned gy = (unsigned)((args.n_portfolios + 32 * mt - 1) / (32 * mt));
+  const unsigned gy = (unsigned)((args.k_count + 32 * mt - 1) / (32 * mt));
   const dim3 grid(gx, gy);
   switch (nb) {
     case 1: return go_nb<1>(mt, native, args, grid, stream);
