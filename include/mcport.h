@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MCP_ABI_VERSION 2
+#define MCP_ABI_VERSION 3
 #define MCP_MAX_ASSETS 64        /* thread-per-path kernels are instantiated for N4 = 4..64 */
 #define MCP_SELECT_BINS 2048     /* radix-select digit: 11 + 11 + 10 bits */
 
@@ -85,11 +85,16 @@ typedef struct {
 } mcp_stats;
 
 /* Raw sufficient statistics of one portfolio on one device: what ranks exchange (one all-gather, merged in rank
- * order: SUM on n, sum, sumsq, below; MIN on min; MAX on max).  `below` = sum of x over this device's paths that sort
- * strictly below the bucket of the low order statistic of the radix select (the CVaR tail, app.py:261-263). */
+ * order: SUM on n, sum, sumsq, below; MIN on min; MAX on max).  SHIFTED sums: sum = sum (x - pivot),
+ * sumsq = sum (x - pivot)^2 with the same pivot on every rank (mcp_pivots: the analytic mean of x), so that
+ * mean = pivot + sum/n and sum (x - mean)^2 = sumsq - sum^2/n do not cancel for a low-volatility portfolio
+ * (np.std(ddof=1), app.py:234, is two-pass).  `below` = this device's paths that sort strictly below the bucket of the low
+ * order statistic of the radix select (the CVaR tail, app.py:261-263), as sum (V - v0) (simple compounding;
+ * sum x = below / v0) or sum x (log). */
 typedef struct {
     double n, sum, sumsq, min, max, below;
-    double pad[2];
+    double pivot;
+    double pad;
 } mcp_record;
 
 int mcp_abi_version(void);
@@ -109,6 +114,19 @@ int mcp_ctx_create(int device, mcp_ctx **out);
  * association. */
 int mcp_ctx_create_multi(const int *devices, int ndev, mcp_ctx **out);
 int mcp_ctx_device_count(const mcp_ctx *ctx);   /* number of shards of the context */
+/* How the shards of the context exchange histograms and records.  The communicator (or the peer mapping) is set up on the
+ * first path-sharded mcp_simulate, not at creation: a portfolio-sharded call (MCP_FLAG_SHARD_PORTFOLIOS) needs neither.
+ * MCP_EXCHANGE_UNSET until then.  When RCCL could not be used and the context fell back to the peer-access kernel,
+ * mcp_ctx_exchange_note() says why (empty string otherwise). */
+enum {
+    MCP_EXCHANGE_UNSET = 0,    /* nothing exchanged yet */
+    MCP_EXCHANGE_NONE = 1,     /* one shard */
+    MCP_EXCHANGE_RCCL = 2,     /* distinct devices, ncclAllReduce / ncclAllGather over xGMI */
+    MCP_EXCHANGE_KERNEL = 3,   /* logical shards of ONE device: a kernel sums the shards' buffers */
+    MCP_EXCHANGE_P2P = 4       /* distinct devices, RCCL unavailable (or MCP_EXCHANGE=p2p): the same kernel over peer access */
+};
+int mcp_ctx_exchange_mode(const mcp_ctx *ctx);
+const char *mcp_ctx_exchange_note(const mcp_ctx *ctx);
 void mcp_ctx_destroy(mcp_ctx *ctx);
 
 /* Large K: the terminal values are produced and reduced in tiles of portfolios so that at most about
@@ -136,60 +154,82 @@ int mcp_sweep_historical(mcp_ctx *ctx, int n_assets, int n_rows, int n_portfolio
 
 /* ---- device-level API: the same kernels as separate enqueue-only steps, for a host that owns the
  *      buffers and the collectives (one process per GPU, torch.distributed over RCCL).  Work buffers
- *      are opaque device memory of the byte sizes given by mcp_ws_bytes(); they must be ZERO when first
+ *      are opaque device memory of the byte sizes given by mcp_ws_bytes(); MCP_WS_HIST must be ZERO when first
  *      used (the steps clear what they consume).  One pass, in this order:
- *          paths -> pass0 -> [all-reduce HIST] -> scan(0) -> hist(1) -> [all-reduce HIST] -> scan(1)
+ *          paths (fused: V_T, moment partials, digit-0 histogram)
+ *                -> [all-reduce HIST] -> scan(0) -> hist(1) -> [all-reduce HIST] -> scan(1)
  *                -> hist(2) -> [all-reduce HIST] -> final -> [all-gather RECORD -> stats]
- *      A single-GPU host skips the bracketed exchanges and passes d_stats to mcp_launch_final. -------- */
+ *      A single-GPU host skips the bracketed exchanges and passes d_stats to mcp_launch_final.  A host that has terminal
+ *      values of its own replaces `paths` by mcp_launch_pass0. -------- */
 
 enum {
-    MCP_WS_PARTIALS = 0,   /* [K][slots(K)][6] double: per-block partials of the streaming passes      */
-    MCP_WS_RECORD = 1,     /* [K] mcp_record: this device's sufficient statistics (all-gathered)        */
-    MCP_WS_STATE = 2,      /* [K][2] select state {u32 prefix, u32 pad, u64 rank}                       */
-    MCP_WS_HIST = 3,       /* [K][2][MCP_SELECT_BINS] uint64: all-reduce SUM after pass0 / hist         */
-    MCP_WS_QUANT = 4,      /* [K] {double x_lo, x_hi, var, level2; u64 n_tail, pad}: identical on all ranks */
-    MCP_WS_STATS = 5,      /* [K] mcp_stats                                                             */
-    MCP_WS_COUNT = 6
+    MCP_WS_PARTIALS = 0,   /* [K][mcp_moment_slots] x 32 B {sum (x-c), sum (x-c)^2, float min V, max V, u64 n}: one per
+                              workgroup (K <= 16) or per 64-path wave tile (K >= 17) of the path kernels          */
+    MCP_WS_RECORD = 1,     /* [K] mcp_record: this device's sufficient statistics (all-gathered)                  */
+    MCP_WS_STATE = 2,      /* [K][2] select state {u32 prefix, u32 pad, u64 rank}                                 */
+    MCP_WS_HIST = 3,       /* [K][2][MCP_SELECT_BINS] uint64: all-reduce SUM after paths / hist                   */
+    MCP_WS_QUANT = 4,      /* [K] {double x_lo, x_hi, var, level2; u64 n_tail, pad}: identical on all ranks       */
+    MCP_WS_STATS = 5,      /* [K] mcp_stats                                                                       */
+    MCP_WS_BELOW = 6,      /* [K][slots(K)] double: per-block tail partials of hist(1) / hist(2)                  */
+    MCP_WS_PIVOT = 7,      /* [K] double: the shift of the moments (host: mcp_pivots, then copy to the device)    */
+    MCP_WS_COUNT = 8
 };
-size_t mcp_ws_bytes(int which, int n_portfolios);
+/* bytes of work buffer `which` for K portfolios and n_paths paths on this device (only MCP_WS_PARTIALS depends on n_paths) */
+size_t mcp_ws_bytes(int which, int n_portfolios, uint64_t n_paths);
+/* MomentPartial slots per portfolio a pass over n_paths fills (informative; mcp_ws_bytes uses it) */
+uint64_t mcp_moment_slots(int n_portfolios, uint64_t n_paths);
 
 /* Number of floats of the packed parameter block for (N, K). */
 size_t mcp_packed_len(int n_assets, int n_portfolios);
 /* Pack mu, lower(chol), W (and portfolio 0's fold block) into the padded device layout (host side, no GPU needed). */
 int mcp_pack_params(int n_assets, int n_portfolios, const float *mu, const float *chol, const float *W,
                     float *packed_out, size_t packed_len);
+/* The shift of the moments, one per portfolio (host side, binary64 from the binary32 inputs): the analytic mean of x,
+ *   simple: c_k = (1 + w_k.mu)^T - 1          log: c_k = expm1(T (w_k.mu + |L^T w_k|^2 / 2)).
+ * A function of the inputs only, hence identical on every rank; 0 where it is not finite. */
+int mcp_pivots(const mcp_params *prm, const float *mu, const float *chol, const float *W, double *pivots_out /* [K] */);
 
 /* Simulate paths [path_begin, path_begin+n_paths) of all K portfolios and store the terminal values:
- * d_terminal is [K][terminal_stride] floats (terminal_stride >= n_paths), 4 B per path and portfolio. */
-int mcp_launch_paths(const mcp_params *prm, const float *d_packed, uint64_t seed, uint64_t path_begin,
-                     uint64_t n_paths, float *d_terminal, uint64_t terminal_stride, void *stream);
+ * d_terminal is [K][terminal_stride] floats (terminal_stride >= n_paths), 4 B per path and portfolio.
+ * With d_partials and d_hist (both or neither) the kernels' epilogue also reduces the paths while V is in registers:
+ * moment partials around d_pivot ([K] doubles, NULL = 0) into d_partials and the digit-0 histogram of the radix select
+ * (key bits 31..21) into d_hist -- what mcp_launch_scan(pass 0) consumes.  (K >= 17: the histogram is one lean read of
+ * V_T enqueued behind the MFMA kernel, whose workgroups hold 512 portfolios.) */
+int mcp_launch_paths(const mcp_params *prm, const float *d_packed, const double *d_pivot, uint64_t seed, uint64_t path_begin,
+                     uint64_t n_paths, float *d_terminal, uint64_t terminal_stride, void *d_partials, void *d_hist,
+                     void *stream);
 
 /* np.percentile(x, (1-alpha)*100) bookkeeping (numpy 2.2 `_compute_virtual_index`/`_get_indexes`,
  * method 'linear'; the q of app.py:259): ranks of the two order statistics and the weight. */
 int mcp_percentile_rank(uint64_t n_total, double alpha, uint64_t *rank_lo, uint64_t *rank_hi, double *gamma);
 
-/* One read of this device's n terminal values per portfolio: {n, sum x, sum x^2, min, max} partials and the
- * digit-0 histogram (key bits 31..21) of the exact radix select on the order-preserving key of the float bits. */
+/* Standalone pass 0 over CALLER-SUPPLIED terminal values (n per portfolio): the same moment partials and digit-0
+ * histogram the fused epilogue of mcp_launch_paths leaves.  d_pivot: [K] doubles or NULL (= 0: raw sums). */
 int mcp_launch_pass0(const mcp_params *prm, const float *d_terminal, uint64_t terminal_stride, uint64_t n,
-                     void *d_partials, void *d_hist, void *stream);
-/* pass 0: partials -> d_record, (rank_lo, rank_hi) of the GLOBAL n -> d_state, descend into the digit holding each
- * rank; pass 1: descend again (and fold the partials of hist pass 1 into d_record).  Clears d_hist. */
+                     const double *d_pivot, void *d_partials, void *d_hist, void *stream);
+/* pass 0: partials -> d_record (with d_pivot, NULL = 0), (rank_lo, rank_hi) of the GLOBAL n -> d_state, descend into the
+ * digit holding each rank; pass 1: descend again (and fold the tail partials of hist pass 1 into d_record).  Clears d_hist. */
 int mcp_launch_scan(const mcp_params *prm, int pass, uint64_t n, uint64_t rank_lo, uint64_t rank_hi, const void *d_partials,
-                    void *d_hist, void *d_state, void *d_record, void *stream);
+                    const void *d_below, const double *d_pivot, void *d_hist, void *d_state, void *d_record, void *stream);
 /* pass 1 (key bits 20..10) / pass 2 (bits 9..0): digit histograms of the keys matching the prefixes in d_state, and the
- * sum of x below the low bucket (CVaR tail, app.py:261-263) into d_partials. */
+ * tail sum below the low bucket (CVaR tail, app.py:261-263) into d_below.  pass 0: the digit-0 histogram alone (d_state
+ * unused; d_pivot, if given, centres the kernel's counting window). */
 int mcp_launch_hist(const mcp_params *prm, int pass, const float *d_terminal, uint64_t terminal_stride, uint64_t n,
-                    const void *d_state, void *d_partials, void *d_hist, void *stream);
+                    const void *d_state, const double *d_pivot, void *d_below, void *d_hist, void *stream);
 /* Last descent -> order statistics -> VaR (numpy `_lerp`) -> d_quant; tail count / in-bucket tail sum from the
  * (global) histogram; local `below` into d_record.  d_stats != NULL (single device): also mean, std (ddof=1), Sharpe,
  * CVaR -> d_stats [K] mcp_stats.  Clears d_hist. */
 int mcp_launch_final(const mcp_params *prm, uint64_t n, double gamma, uint64_t rank_lo, uint64_t rank_hi,
-                     const void *d_partials, void *d_hist, const void *d_state, void *d_record, void *d_quant,
+                     const void *d_below, void *d_hist, const void *d_state, void *d_record, void *d_quant,
                      void *d_stats, void *stream);
 /* Multi-GPU: merge the all-gathered records of `world` ranks, d_gathered [world][K] mcp_record in rank order, and
  * finish -> d_stats [K] mcp_stats. */
 int mcp_launch_stats(const mcp_params *prm, int world, const void *d_gathered, const void *d_quant, void *d_stats,
                      void *stream);
+/* Exchange between logical shards that live in ONE process (several shards of one device, or devices with peer access):
+ * every one of the `n_bufs` (<= 8) device buffers <- their element-wise sum (u64 words).  The kernel form of the histogram
+ * all-reduce; the caller orders it after the producers and before the consumers of every buffer (events). */
+int mcp_launch_sum_u64(void *const *d_bufs, int n_bufs, size_t words, void *stream);
 
 /* The normal generator on its own: d_z[i] = inverse-CDF normal (SPEC.md section 3) of the 32-bit word d_x[i]. */
 int mcp_launch_normals(const uint32_t *d_x, uint64_t n, float *d_z, void *stream);

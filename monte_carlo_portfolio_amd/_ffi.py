@@ -17,7 +17,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MCP_LIB_PATH") or os.path.join(_PKG, "libmcport.so")     # MCP_LIB_PATH: a lab build (tools/kernel_lab.py)
 CSRC = os.path.join(_PKG, "csrc")
 
-MCP_ABI_VERSION = 2
+MCP_ABI_VERSION = 3
 MCP_MAX_ASSETS = 64
 MCP_SELECT_BINS = 2048
 MCP_COMPOUND = {"simple": 0, "log": 1}
@@ -25,8 +25,9 @@ MCP_FLAG_NATIVE_MATH = 1
 MCP_FLAG_FOLD = 2
 MCP_FLAG_SHARD_PORTFOLIOS = 4
 MCP_E_ARG, MCP_E_NODEVICE, MCP_E_NOMEM, MCP_E_UNSUPPORTED, MCP_E_HIP, MCP_E_COMM = -1, -2, -3, -4, -5, -6
-(WS_PARTIALS, WS_RECORD, WS_STATE, WS_HIST, WS_QUANT, WS_STATS) = range(6)
-WS_COUNT = 6
+(WS_PARTIALS, WS_RECORD, WS_STATE, WS_HIST, WS_QUANT, WS_STATS, WS_BELOW, WS_PIVOT) = range(8)
+WS_COUNT = 8
+(EXCHANGE_UNSET, EXCHANGE_NONE, EXCHANGE_RCCL, EXCHANGE_KERNEL, EXCHANGE_P2P) = range(5)
 
 
 class McpError(RuntimeError):
@@ -58,7 +59,10 @@ STATS_DTYPE = np.dtype([
 assert STATS_DTYPE.itemsize == ctypes.sizeof(McpStats)
 
 RECORD_DTYPE = np.dtype([("n", np.float64), ("sum", np.float64), ("sumsq", np.float64), ("min", np.float64),
-                         ("max", np.float64), ("below", np.float64), ("pad", np.float64, (2,))])
+                         ("max", np.float64), ("below", np.float64), ("pivot", np.float64), ("pad", np.float64)])
+# one moment partial of the path kernels' epilogue (csrc/mcp_stats_kernels.h: MomentPartial)
+PARTIAL_DTYPE = np.dtype([("s1", np.float64), ("s2", np.float64), ("vmin", np.float32), ("vmax", np.float32), ("n", np.uint64)])
+assert PARTIAL_DTYPE.itemsize == 32
 QUANT_DTYPE = np.dtype([("x_lo", np.float64), ("x_hi", np.float64), ("var", np.float64), ("level2", np.float64),
                         ("n_tail", np.uint64), ("pad", np.uint64)])
 RECORD_DOUBLES = RECORD_DTYPE.itemsize // 8
@@ -78,22 +82,27 @@ SIGNATURES = {
     "mcp_ctx_create": (_int, [_int, ctypes.POINTER(_vp)]),
     "mcp_ctx_create_multi": (_int, [ctypes.POINTER(_int), _int, ctypes.POINTER(_vp)]),
     "mcp_ctx_device_count": (_int, [_vp]),
+    "mcp_ctx_exchange_mode": (_int, [_vp]),
+    "mcp_ctx_exchange_note": (ctypes.c_char_p, [_vp]),
     "mcp_ctx_set_terminal_budget": (_int, [_vp, ctypes.c_size_t]),
     "mcp_ctx_destroy": (None, [_vp]),
     "mcp_simulate": (_int, [_vp, _PP, _f32p, _f32p, _f32p, _u64, _u64, _u64, _vp, _vp]),
     "mcp_sweep_historical": (_int, [_vp, _int, _int, _int, _f64p, _f64p, _f64p, _f64p, ctypes.c_double, ctypes.c_double,
                                     _f64p, _f64p, _f64p, _f64p, _f64p]),
-    "mcp_ws_bytes": (ctypes.c_size_t, [_int, _int]),
+    "mcp_ws_bytes": (ctypes.c_size_t, [_int, _int, _u64]),
+    "mcp_moment_slots": (_u64, [_int, _u64]),
+    "mcp_pivots": (_int, [_PP, _f32p, _f32p, _f32p, _f64p]),
     "mcp_packed_len": (ctypes.c_size_t, [_int, _int]),
     "mcp_pack_params": (_int, [_int, _int, _f32p, _f32p, _f32p, _f32p, ctypes.c_size_t]),
-    "mcp_launch_paths": (_int, [_PP, _vp, _u64, _u64, _u64, _vp, _u64, _vp]),
+    "mcp_launch_paths": (_int, [_PP, _vp, _vp, _u64, _u64, _u64, _vp, _u64, _vp, _vp, _vp]),
     "mcp_percentile_rank": (_int, [_u64, ctypes.c_double, ctypes.POINTER(_u64), ctypes.POINTER(_u64),
                                    ctypes.POINTER(ctypes.c_double)]),
-    "mcp_launch_pass0": (_int, [_PP, _vp, _u64, _u64, _vp, _vp, _vp]),
-    "mcp_launch_scan": (_int, [_PP, _int, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
-    "mcp_launch_hist": (_int, [_PP, _int, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "mcp_launch_pass0": (_int, [_PP, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "mcp_launch_scan": (_int, [_PP, _int, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mcp_launch_hist": (_int, [_PP, _int, _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
     "mcp_launch_final": (_int, [_PP, _u64, ctypes.c_double, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mcp_launch_stats": (_int, [_PP, _int, _vp, _vp, _vp, _vp]),
+    "mcp_launch_sum_u64": (_int, [ctypes.POINTER(_vp), _int, ctypes.c_size_t, _vp]),
     "mcp_launch_normals": (_int, [_vp, _u64, _vp, _vp]),
     "mcp_icdf_table": (_int, [_f32p, ctypes.c_size_t]),
     "mcp_float_to_key": (ctypes.c_uint32, [ctypes.c_float]),
@@ -144,7 +153,10 @@ def preload_rccl() -> None:
         cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
         if os.path.exists(cand):
             try:
-                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+                # default (RTLD_LOCAL) binding: the library's later dlopen("librccl.so.1") finds this copy by SONAME all the
+                # same, and librccl's symbols stay out of the global scope -- promoted to RTLD_GLOBAL they interpose symbols of
+                # a torch imported LATER in the same process, which then aborts at exit ("double free or corruption")
+                ctypes.CDLL(cand)
             except OSError:
                 pass
 
@@ -190,6 +202,13 @@ def pack_params(mu: np.ndarray, chol: np.ndarray, W: np.ndarray) -> np.ndarray:
     k = W.shape[0]
     out = np.zeros(lib().mcp_packed_len(n, k), np.float32)
     check(lib().mcp_pack_params(n, k, mu, chol, W, out, out.size))
+    return out
+
+
+def pivots(prm: McpParams, mu: np.ndarray, chol: np.ndarray, W: np.ndarray) -> np.ndarray:
+    """[K] shifts of the moments (include/mcport.h: mcp_pivots): the analytic mean of x per portfolio, pure host arithmetic."""
+    out = np.zeros(W.shape[0], np.float64)
+    check(lib().mcp_pivots(ctypes.byref(prm), mu, chol, W, out))
     return out
 
 

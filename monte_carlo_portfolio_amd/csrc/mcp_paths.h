@@ -1,8 +1,11 @@
 // mcp_paths.h -- the fused Monte Carlo path kernel (template; instantiated per NB in mcp_paths_inst.hip).
 //
-//   mc_paths_kernel   N1+N2 of SURVEY.md section 8(a): Philox4x32-10 -> normals (inverse CDF) -> r = mu + L z ->
+//   mc_paths_kernel   N1+N2+N3 of SURVEY.md section 8(a): Philox4x32-10 -> normals (inverse CDF) -> r = mu + L z ->
 //                     rho = w.r -> V <- V(1+rho) over T steps, entirely in registers; writes V_T
-//                     (4 B/path, coalesced).  All statistics are separate streaming passes over V_T.
+//                     (4 B/path, coalesced).  Epilogue (when the launch carries a statistics workspace): with V still in
+//                     registers, x = V/v0 - 1, the shifted moments {n, sum (x-c), sum (x-c)^2, min, max} in fp64 by
+//                     wavefront shuffle reduction -> ONE partial per workgroup and portfolio, and the digit-0 histogram
+//                     of the radix select in LDS -> global.  The select's two remaining digits are streaming passes.
 //                     Conventions inherited from the reference: fixed-weight portfolio return
 //                     `returns_df @ ws` (app.py:710), compounding prod(1+r) (app.py:249, app.py:253).
 //
@@ -16,6 +19,7 @@
 
 #include "../../include/mcport.h"
 #include "mcp_device.h"
+#include "mcp_stats_kernels.h"
 
 #ifndef MCP_MIN_WAVES
 #define MCP_MIN_WAVES 6     // __launch_bounds__ 2nd argument for N <= 16, one portfolio: at least 6 waves/SIMD (the kernel needs 74
@@ -36,6 +40,14 @@ struct PathArgs {
   const float* __restrict__ packed;   // [mu N4][L row pairs N4(N4/2+1)][W Kpad*N4]  (mcp_pack_params)
   float* __restrict__ terminal;       // [K][stride]
   const float4* __restrict__ tables;  // [ICDF_ENTRIES] inverse-CDF coefficient table (device copy of mcp_icdf_table.inc)
+  // fused statistics epilogue (all three NULL: terminal values only)
+  const double* __restrict__ pivot;   // [K] shift c of the moments (mcp_pivots), NULL = 0
+  MomentPartial* __restrict__ partials;   // [K][slots]
+  unsigned long long* __restrict__ hist;  // [K][2][MCP_SELECT_BINS]: digit-0 histogram into [k][0] (K <= 16 kernels only)
+  uint64_t slots;                     // MomentPartial slots per portfolio (= gridDim.x of mc_paths_kernel, n/64 tiles of the sweeps)
+  double v0d;                         // (double)(float)v0
+  double inv_v0d;                     // 1 / v0d; exact when v0 is a power of two (v0_pow2), then x = fma(V, inv_v0d, -1) IS V/v0 - 1
+  int32_t v0_pow2;
   uint64_t seed, path_begin, n_paths, stride;
   int32_t n_steps, n_portfolios, k_begin, compounding;
   int32_t k_count;                    // sweep kernels: portfolios [k_begin, k_begin + k_count) belong to this launch
@@ -57,6 +69,36 @@ __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+__device__ __forceinline__ float wave_minf(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_maxf(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// h[digit] += 1 for the active lanes.  Terminal values cluster (V_T ~ 1 +- 0.2 hits a handful of digit-0 bins), and 64
+// lanes on one LDS address serialise; so up to four distinct digits per wave are counted by ballot and added once.
+// Every lane of the wave must call it (ballots inside).
+__device__ __forceinline__ void lds_hist_add(uint32_t* h, uint32_t digit, bool active) {
+  unsigned long long todo = __ballot(active);
+  const int lane = threadIdx.x & 63;
+#pragma unroll 1
+  for (int it = 0; it < 4 && todo; it++) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)digit, leader);
+    const bool same = active && digit == d0;
+    const unsigned long long m = __ballot(same);
+    if (lane == leader) atomicAdd(&h[d0], (uint32_t)__popcll(m));
+    todo &= ~m;
+    active = active && !same;
+  }
+  if (active) atomicAdd(&h[digit], 1u);
 }
 
 // x = V_T/V0 - 1 (simple) or expm1(S_T) (log); double, as the host computes it (mcp_terminal_to_x).
@@ -92,7 +134,23 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
   if constexpr (LDS_MU) {
     if (threadIdx.x < N4) { s_par0[threadIdx.x] = mu[threadIdx.x]; if (LDS_W) s_par0[N4 + threadIdx.x] = Wk[threadIdx.x]; }
   }
-  if constexpr (!NATIVE) __syncthreads();
+  // statistics epilogue (N3): per-wave moment accumulators and the digit-0 histogram of one portfolio at a time
+  __shared__ uint32_t s_hist[MCP_SELECT_BINS];
+  __shared__ double s_mom[PATH_BLOCK / 64][KT][2];
+  __shared__ float s_ext[PATH_BLOCK / 64][KT][2];
+  __shared__ unsigned long long s_cnt[PATH_BLOCK / 64];
+  // The epilogue's own arguments (pivot, partials, hist, slots, v0d: 13 dwords) are read from the kernel-argument segment
+  // AFTER the step loop, through a pointer the compiler cannot see through: loaded up front they would sit in SGPRs for the
+  // whole walk, and the kernel has none to spare (the Cholesky factor is fed from SGPRs): they spilled into VGPR lanes.
+  typedef const __attribute__((address_space(4))) PathArgs* cargs_p;
+  cargs_p kargs = (cargs_p)__builtin_amdgcn_kernarg_segment_ptr();
+  for (int i = threadIdx.x; i < MCP_SELECT_BINS; i += PATH_BLOCK) s_hist[i] = 0u;
+  if (threadIdx.x < (PATH_BLOCK / 64) * KT) {
+    (&s_mom[0][0][0])[2 * threadIdx.x] = 0.0; (&s_mom[0][0][0])[2 * threadIdx.x + 1] = 0.0;
+    (&s_ext[0][0][0])[2 * threadIdx.x] = __builtin_inff(); (&s_ext[0][0][0])[2 * threadIdx.x + 1] = -__builtin_inff();
+  }
+  if (threadIdx.x < PATH_BLOCK / 64) s_cnt[threadIdx.x] = 0ull;
+  __syncthreads();
   const IcdfConsts kc = icdf_consts();
   PhiloxKeys ks = philox_keys((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
 #if MCP_EXP_VKEYS
@@ -196,6 +254,70 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
         for (int k = 0; k < KT; k++)
           if (k < kt) a.terminal[(size_t)(a.k_begin + k) * a.stride + p[e]] = V[e][k];
       }
+    }
+
+    // ---- fused statistics epilogue: V is still in registers ----
+    asm volatile("" : "+s"(kargs));
+    if (kargs->partials != nullptr) {                      // wave-uniform (kernel argument)
+      const double* __restrict__ e_pivot = kargs->pivot;
+      unsigned long long* __restrict__ e_hist = kargs->hist;
+      const double e_v0d = kargs->v0d;
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));                        // nothing derived from it (LDS addresses) is hoisted above the step loop
+      const int lane = tid & 63, wv = tid >> 6;
+      unsigned long long cnt = 0;
+#pragma unroll
+      for (int e = 0; e < PPT; e++) cnt += (unsigned long long)__popcll(__ballot(live[e]));
+      if (lane == 0) s_cnt[wv] += cnt;
+#pragma unroll 1
+      for (int k = 0; k < kt; k++) {
+        const double c = e_pivot ? e_pivot[a.k_begin + k] : 0.0;
+        double d1 = 0.0, d2 = 0.0;
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+#pragma unroll
+        for (int e = 0; e < PPT; e++) {
+          float v = V[e][0];
+#pragma unroll
+          for (int kk = 1; kk < KT; kk++) v = (kk == k) ? V[e][kk] : v;      // register select (k is a run-time index)
+          if (live[e]) {
+            const double d = terminal_to_x(v, e_v0d, logc ? MCP_COMPOUND_LOG : MCP_COMPOUND_SIMPLE) - c;
+            d1 += d;
+            d2 = __builtin_fma(d, d, d2);
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+          }
+          if (e_hist) lds_hist_add(s_hist, float_to_key(v) >> 21, live[e]);
+        }
+        d1 = wave_sum(d1); d2 = wave_sum(d2); mn = wave_minf(mn); mx = wave_maxf(mx);
+        if (lane == 0) {                                   // this wave's own slot: no race, fixed order over the tiles
+          s_mom[wv][k][0] += d1; s_mom[wv][k][1] += d2;
+          s_ext[wv][k][0] = fminf(s_ext[wv][k][0], mn); s_ext[wv][k][1] = fmaxf(s_ext[wv][k][1], mx);
+        }
+        if (e_hist) {                                      // flush portfolio k's digit-0 counts (read-and-clear)
+          __syncthreads();
+          unsigned long long* out = e_hist + (size_t)(a.k_begin + k) * 2 * MCP_SELECT_BINS;
+          for (int i = tid; i < MCP_SELECT_BINS; i += PATH_BLOCK) {
+            const uint32_t h = s_hist[i];
+            if (h) { atomicAdd(&out[i], (unsigned long long)h); s_hist[i] = 0u; }
+          }
+          __syncthreads();
+        }
+      }
+    }
+  }
+
+  asm volatile("" : "+s"(kargs));
+  if (kargs->partials != nullptr) {
+    __syncthreads();
+    if ((int)threadIdx.x < kt) {                           // one partial per workgroup and portfolio, waves in order
+      const int k = threadIdx.x;
+      MomentPartial o;
+      o.s1 = (s_mom[0][k][0] + s_mom[1][k][0]) + (s_mom[2][k][0] + s_mom[3][k][0]);
+      o.s2 = (s_mom[0][k][1] + s_mom[1][k][1]) + (s_mom[2][k][1] + s_mom[3][k][1]);
+      o.vmin = fminf(fminf(s_ext[0][k][0], s_ext[1][k][0]), fminf(s_ext[2][k][0], s_ext[3][k][0]));
+      o.vmax = fmaxf(fmaxf(s_ext[0][k][1], s_ext[1][k][1]), fmaxf(s_ext[2][k][1], s_ext[3][k][1]));
+      o.n = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+      kargs->partials[(size_t)(a.k_begin + k) * kargs->slots + blockIdx.x] = o;
     }
   }
 }

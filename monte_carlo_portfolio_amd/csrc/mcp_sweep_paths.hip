@@ -27,6 +27,53 @@ namespace mcp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Fused moments of the sweep kernels (N3): the wave holds V for 32 MT portfolios x 64 paths in the MFMA C/D layout (lane l,
+// register g of tile (mt, nt): portfolio k_base + 32 mt + (g&3) + 8 (g>>2) + 4 (l>>5), path path0 + 32 nt + (l&31)).  Per
+// portfolio: x = V/v0 - 1 (or expm1 S), d = x - c_k, {sum d, sum d^2, min V, max V} over the wave's 64 paths -- the two
+// path tiles in the lane, then a shuffle reduction over the 32 lanes of the half-wave -- and ONE MomentPartial per portfolio
+// and wave tile, slot `tile` (= global 64-path tile index).  Dead paths (>= n_paths) contribute nothing.
+template <int MT, bool LOGC>
+__device__ __forceinline__ void sweep_moments(const PathArgs& a, const f32x16 (&V)[MT][2], int k_base, uint64_t path0) {
+  const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+  if (path0 >= a.n_paths) return;                          // wave-uniform: a wave tile beyond the range has no slot
+  const bool live0 = path0 + col < a.n_paths, live1 = path0 + 32 + col < a.n_paths;
+  const uint64_t left = a.n_paths - path0;
+  const unsigned long long n_tile = left < 64 ? left : 64;
+  const uint64_t tile = path0 / SWEEP_TILE_PATHS;
+  const float inf = __builtin_inff();
+#pragma unroll
+  for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+      const int k = k_base + 32 * mt + (g & 3) + 8 * (g >> 2) + 4 * half;
+      const bool mine = k < a.n_portfolios;                // rows beyond K are zero-weight padding
+      const double c = (mine && a.pivot) ? a.pivot[k] : 0.0;
+      const float v0 = V[mt][0][g], v1 = V[mt][1][g];
+      double x0, x1;
+      if constexpr (LOGC) { x0 = expm1((double)v0); x1 = expm1((double)v1); }
+      else if (a.v0_pow2) { x0 = __builtin_fma((double)v0, a.inv_v0d, -1.0); x1 = __builtin_fma((double)v1, a.inv_v0d, -1.0); }
+      else { x0 = (double)v0 / a.v0d - 1.0; x1 = (double)v1 / a.v0d - 1.0; }
+      const double d0 = live0 ? x0 - c : 0.0, d1 = live1 ? x1 - c : 0.0;
+      double s1 = d0 + d1;
+      double s2 = __builtin_fma(d0, d0, d1 * d1);
+      float mn = fminf(live0 ? v0 : inf, live1 ? v1 : inf);
+      float mx = fmaxf(live0 ? v0 : -inf, live1 ? v1 : -inf);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {                   // xor offsets < 32 stay inside the half-wave
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+        mn = fminf(mn, __shfl_xor(mn, o, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      }
+      if (col == 0 && mine) {
+        MomentPartial m;
+        m.s1 = s1; m.s2 = s2; m.vmin = mn; m.vmax = mx; m.n = n_tile;
+        a.partials[(size_t)k * a.slots + tile] = m;
+      }
+    }
+  }
+}
+
 #if MCP_SWEEP_PART == 0
 template <int NB, int MT, bool NATIVE, bool LOGC>
 __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs a) {
@@ -120,6 +167,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
         if (path < a.n_paths && k < a.n_portfolios) a.terminal[(size_t)k * a.stride + path] = V[mt][nt][q];
       }
     }
+  if (a.partials) sweep_moments<MT, LOGC>(a, V, k_base, wave_path0);
 }
 
 #endif  // MCP_SWEEP_PART == 0
@@ -243,6 +291,7 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
         if (path < a.n_paths && k < a.n_portfolios) a.terminal[(size_t)k * a.stride + path] = V[mt][nt][q];
       }
     }
+  if (a.partials) sweep_moments<MT, LOGC>(a, V, k_base, path0);
 }
 
 template <int NB>

@@ -37,23 +37,33 @@ class FakeKernels:
     def _np(t, dtype):
         return t.numpy().view(dtype)
 
-    def paths(self, prm, packed, seed, path_begin, n, terminal):
+    def paths(self, prm, packed, pivot, seed, path_begin, n, terminal, partials, hist):
         comp = "log" if prm.compounding == 1 else "simple"
         terminal.numpy()[:, :n] = mc_oracle.simulate(self.mu, self.L, self.W, prm.n_steps, n, seed, path_begin=path_begin,
                                                      v0=prm.v0, compounding=comp, n_threads=2)
+        if partials is not None:                     # the fused epilogue: moment partials + digit-0 histogram
+            self.pass0(prm, terminal, n, pivot, partials, hist)
 
     # ---- statistics pipeline: same buffers, same read-and-clear protocol as mcp_stats_kernels.hip -----------------
     def _x(self, prm, v):
         return ref_stats.terminal_to_x(v, prm.v0, "log" if prm.compounding == 1 else "simple")
 
-    def pass0(self, prm, terminal, n, partials, hist):
+    def _below_term(self, prm, v):
+        """what the select passes accumulate for the CVaR tail: sum (V - v0) (simple) or sum expm1(S) (log)"""
+        if prm.compounding == 1:
+            return np.expm1(v.astype(np.float64))
+        return v.astype(np.float64) - np.float64(np.float32(prm.v0))
+
+    def pass0(self, prm, terminal, n, pivot, partials, hist):
         K = prm.n_portfolios
-        part = self._np(partials, np.float64).reshape(K, -1, 6)
+        part = partials.numpy().view(np.uint8)[:K * (partials.numel() * 8 // K // 32) * 32].view(_ffi.PARTIAL_DTYPE).reshape(K, -1)
         h = self._np(hist, np.int64).reshape(K, 2, BINS)
+        c = np.zeros(K) if pivot is None else pivot.numpy().view(np.float64)[:K]
         for k in range(K):
             v = terminal.numpy()[k, :n]
-            x = self._x(prm, v)
-            part[k, 0, :5] = [x.size, x.sum(), (x * x).sum(), x.min() if n else np.inf, x.max() if n else -np.inf]
+            d = self._x(prm, v) - c[k]
+            part[k] = (0.0, 0.0, np.inf, -np.inf, 0)
+            part[k, 0] = (d.sum(), (d * d).sum(), v.min() if n else np.inf, v.max() if n else -np.inf, n)
             h[k, 0] += np.bincount(_keys(v) >> np.uint32(21), minlength=BINS)
 
     def _descend(self, p, hh, prefix, rank):
@@ -63,66 +73,82 @@ class FakeKernels:
         before = int(cum[d - 1]) if d > 0 else 0
         return (d if p == 0 else ((prefix << bits) | d) & 0xFFFFFFFF), rank - before, int(hh[d])
 
-    def scan(self, prm, p, n, lo, hi, partials, hist, state, record):
+    def scan(self, prm, p, n, lo, hi, partials, below, pivot, hist, state, record):
         K = prm.n_portfolios
-        part = self._np(partials, np.float64).reshape(K, -1, 6)
         h = self._np(hist, np.int64).reshape(K, 2, BINS)
         s = self._np(state, np.uint64).reshape(K, 2, 2)
         rec = self._np(record, np.float64).reshape(K, 8)
+        bel = self._np(below, np.float64).reshape(K, -1)
+        c = np.zeros(K) if pivot is None else pivot.numpy().view(np.float64)[:K]
         for k in range(K):
             if p == 0:
-                rec[k] = list(part[k, 0, :5]) + [0.0, 0.0, 0.0]
+                part = partials.numpy().view(np.uint8)[:K * (partials.numel() * 8 // K // 32) * 32].view(_ffi.PARTIAL_DTYPE).reshape(K, -1)[k]
+                m = int(part["n"].sum())
+                vmin, vmax = part["vmin"].min(), part["vmax"].max()
+                rec[k] = [m, part["s1"].sum(), part["s2"].sum(),
+                          self._x(prm, np.array([vmin], np.float32))[0] if m else np.inf,
+                          self._x(prm, np.array([vmax], np.float32))[0] if m else -np.inf, 0.0, c[k], 0.0]
             else:
-                rec[k, 5] = part[k, 0, 5]
+                rec[k, 5] = bel[k, 0]
+            shared = p == 0 or (s[k, 0, 0] & np.uint64(0xFFFFFFFF)) == (s[k, 1, 0] & np.uint64(0xFFFFFFFF))
+            new = []
             for w in range(2):
                 prefix, rank = (0, (lo, hi)[w]) if p == 0 else (int(s[k, w, 0] & np.uint64(0xFFFFFFFF)), int(s[k, w, 1]))
-                pre, r, _ = self._descend(p, h[k, 0 if p == 0 else w], prefix, rank)
-                s[k, w] = [pre, r]
+                pre, r, _ = self._descend(p, h[k, 0 if shared else w], prefix, rank)
+                new.append([pre, r])
+            s[k] = new
             h[k] = 0
 
-    def hist(self, prm, p, terminal, n, state, partials, hist):
+    def hist(self, prm, p, terminal, n, state, pivot, below, hist):
         shift, bits, pshift = SHAPE[p]
         K = prm.n_portfolios
-        s = self._np(state, np.uint64).reshape(K, 2, 2)
         h = self._np(hist, np.int64).reshape(K, 2, BINS)
-        part = self._np(partials, np.float64).reshape(K, -1, 6)
+        if p == 0:                                   # digit 0 alone (behind the MFMA sweep kernels)
+            for k in range(K):
+                h[k, 0] += np.bincount(_keys(terminal.numpy()[k, :n]) >> np.uint32(21), minlength=BINS)
+            return
+        s = self._np(state, np.uint64).reshape(K, 2, 2)
+        bel = self._np(below, np.float64).reshape(K, -1)
         for k in range(K):
             v = terminal.numpy()[k, :n]
             keys = _keys(v)
             digit = (keys >> np.uint32(shift)) & np.uint32((1 << bits) - 1)
             pre = keys >> np.uint32(pshift)
-            for w in range(2):
-                prefix = np.uint32(s[k, w, 0] & np.uint64(0xFFFFFFFF))
-                h[k, w] += np.bincount(digit[pre == prefix], minlength=BINS)
             pa = np.uint32(s[k, 0, 0] & np.uint64(0xFFFFFFFF))
+            pb = np.uint32(s[k, 1, 0] & np.uint64(0xFFFFFFFF))
+            h[k, 0] += np.bincount(digit[pre == pa], minlength=BINS)
+            if pb != pa:                             # both targets in one bucket: only [k][0] is filled
+                h[k, 1] += np.bincount(digit[pre == pb], minlength=BINS)
             sel = pre < pa
             if p == 2:
                 sel &= (pre >> np.uint32(11)) == (pa >> np.uint32(11))
-            part[k, 0, 5] = self._x(prm, v[sel]).sum()
+            bel[k, 0] = self._below_term(prm, v[sel]).sum()
 
-    def final(self, prm, n, gamma, lo, hi, partials, hist, state, record, quant, stats):
+    def final(self, prm, n, gamma, lo, hi, below, hist, state, record, quant, stats):
         K = prm.n_portfolios
-        part = self._np(partials, np.float64).reshape(K, -1, 6)
+        bel = self._np(below, np.float64).reshape(K, -1)
         h = self._np(hist, np.int64).reshape(K, 2, BINS)
         s = self._np(state, np.uint64).reshape(K, 2, 2)
         rec = self._np(record, np.float64).reshape(K, 8)
         q = quant.numpy().view(np.uint8)[:K * _ffi.QUANT_DTYPE.itemsize].view(_ffi.QUANT_DTYPE)
         for k in range(K):
             pres = [int(s[k, w, 0] & np.uint64(0xFFFFFFFF)) for w in range(2)]
-            keys = [self._descend(2, h[k, w], pres[w], int(s[k, w, 1]))[0] for w in range(2)]
+            shared = pres[0] == pres[1]
+            hh = [h[k, 0], h[k, 0 if shared else 1]]
+            keys = [self._descend(2, hh[w], pres[w], int(s[k, w, 1]))[0] for w in range(2)]
             a, b = [self._x(prm, np.array([_key_to_float(key)], np.float32))[0] for key in keys]
             d = b - a
             var = a + d * gamma if gamma < 0.5 else b - d * (1 - gamma)
             cnt, level2 = 0, 0.0
-            for w in range(2 if pres[1] != pres[0] else 1):          # walk the digits of the last bucket(s): x <= var literally
-                for dd in np.nonzero(h[k, w, :1024])[0]:
+            for w in range(1 if shared else 2):                      # walk the digits of the last bucket(s): x <= var literally
+                for dd in np.nonzero(hh[w][:1024])[0]:
                     x = self._x(prm, np.array([_key_to_float((pres[w] << 10) | int(dd))], np.float32))[0]
                     if x <= var:
-                        cnt += int(h[k, w, dd])
-                        level2 += float(h[k, w, dd]) * x
+                        cnt += int(hh[w][dd])
+                        level2 += float(hh[w][dd]) * x
             n_tail = (lo - int(s[k, 0, 1])) + cnt
             q[k] = (a, b, var, level2, n_tail, 0)
-            rec[k, 5] += part[k, 0, 5]
+            rec[k, 5] += bel[k, 0]
             h[k] = 0
         if stats is not None:
             self._finish(prm, rec, q, stats)
@@ -135,17 +161,26 @@ class FakeKernels:
         m[:, [0, 1, 2, 5]] = g[:, :, [0, 1, 2, 5]].sum(axis=0)
         m[:, 3] = g[:, :, 3].min(axis=0)
         m[:, 4] = g[:, :, 4].max(axis=0)
+        m[:, 6] = g[0, :, 6]                          # the pivot is the same on every rank
         self._finish(prm, m, q, stats)
+
+    def sum_u64(self, bufs, words):
+        total = sum(b.numpy()[:words].astype(np.int64) for b in bufs)
+        for b in bufs:
+            b.numpy()[:words] = total
 
     @staticmethod
     def _finish(prm, m, q, stats):
         K = prm.n_portfolios
         out = stats.numpy().view(np.uint8)[:K * _ffi.STATS_DTYPE.itemsize].view(_ffi.STATS_DTYPE)
+        v0 = np.float64(np.float32(prm.v0))
         for k in range(K):
             n, s1, s2 = m[k, 0], m[k, 1], m[k, 2]
-            mean = s1 / n
-            m2 = max(s2 - s1 * mean, 0.0)
+            dm = s1 / n
+            mean = m[k, 6] + dm                       # shifted sums around the pivot
+            m2 = max(s2 - s1 * dm, 0.0)
             std = np.sqrt(m2 / (n - 1)) if n > 1 else 0.0
-            n_tail, sum_tail = int(q[k]["n_tail"]), m[k, 5] + q[k]["level2"]
+            below_x = m[k, 5] if prm.compounding == 1 else m[k, 5] / v0
+            n_tail, sum_tail = int(q[k]["n_tail"]), below_x + q[k]["level2"]
             out[k] = (int(n), n_tail, mean, m2, std, (mean - prm.rf) / std if std > 0 else 0.0, q[k]["var"],
                       sum_tail / n_tail if n_tail > 0 else q[k]["var"], m[k, 3], m[k, 4], sum_tail, q[k]["x_lo"], q[k]["x_hi"])

@@ -34,13 +34,21 @@ def test_struct_layouts(mcp_lib):
     assert ctypes.sizeof(_ffi.McpParams) == 48
     assert ctypes.sizeof(_ffi.McpStats) == 104 == _ffi.STATS_DTYPE.itemsize
     assert _ffi.RECORD_DTYPE.itemsize == 64 and _ffi.QUANT_DTYPE.itemsize == 48
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_RECORD, 3) == 3 * 64
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_QUANT, 3) == 3 * 48
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_STATS, 3) == 3 * 104
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_HIST, 2) == 2 * 2 * 2048 * 8
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_PARTIALS, 2) == 2 * 2048 * 6 * 8 and mcp_lib.mcp_ws_bytes(_ffi.WS_PARTIALS, 10_000) == 10_000 * 8 * 6 * 8
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_STATE, 5) == 5 * 2 * 16
-    assert mcp_lib.mcp_ws_bytes(_ffi.WS_COUNT, 5) == 0 and mcp_lib.mcp_ws_bytes(0, 0) == 0
+    n = 1_000_000
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_RECORD, 3, n) == 3 * 64
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_QUANT, 3, n) == 3 * 48
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_STATS, 3, n) == 3 * 104
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_HIST, 2, n) == 2 * 2 * 2048 * 8
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_STATE, 5, n) == 5 * 2 * 16
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_PIVOT, 5, n) == 5 * 8
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_BELOW, 2, n) == 2 * 2048 * 8 and mcp_lib.mcp_ws_bytes(_ffi.WS_BELOW, 10_000, n) == 10_000 * 1 * 8
+    # moment partials (32 B each): one per workgroup of the one-lane-per-path kernels (256 paths, at most 8,192 workgroups) up to
+    # 16 portfolios, one per 64-path wave tile of the MFMA sweep kernels from 17 on
+    assert mcp_lib.mcp_moment_slots(1, n) == 3907 and mcp_lib.mcp_moment_slots(16, 10**8) == 8192 and mcp_lib.mcp_moment_slots(1, 0) == 1
+    assert mcp_lib.mcp_moment_slots(17, n) == 15625 and mcp_lib.mcp_moment_slots(10_000, 131072) == 2048
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_PARTIALS, 2, n) == 2 * 3907 * 32 and mcp_lib.mcp_ws_bytes(_ffi.WS_PARTIALS, 10_000, 131072) == 10_000 * 2048 * 32
+    assert _ffi.PARTIAL_DTYPE.itemsize == 32
+    assert mcp_lib.mcp_ws_bytes(_ffi.WS_COUNT, 5, n) == 0 and mcp_lib.mcp_ws_bytes(0, 0, n) == 0
 
 
 def test_pack_params_layout(mcp_lib):
@@ -71,6 +79,27 @@ def test_pack_params_layout(mcp_lib):
     np.testing.assert_allclose(F[1:1 + N], (Lt.T @ W[0].astype(np.float64)).astype(np.float32), rtol=2e-7)
     assert np.all(F[1 + N:] == 0)
     assert np.array_equal(Wp[:K, :N], W) and np.all(Wp[:K, N:] == 0) and np.all(Wp[K:] == 0)
+
+
+def test_pivots_are_the_analytic_mean(mcp_lib):
+    """mcp_pivots: c = (1 + w.mu)^T - 1 (simple) / expm1(T (w.mu + w'Sigma w / 2)) (log), binary64 from the binary32 inputs --
+    the shift every rank uses for its moment sums."""
+    rng = np.random.default_rng(3)
+    N, K, T = 5, 4, 252
+    mu = rng.normal(4e-4, 2e-4, N).astype(np.float32)
+    A = rng.normal(size=(N, N)) * 0.01
+    L = np.linalg.cholesky(A @ A.T + 1e-5 * np.eye(N)).astype(np.float32)
+    W = rng.dirichlet(np.ones(N), K).astype(np.float32)
+    m = W.astype(np.float64) @ mu.astype(np.float64)
+    got = _ffi.pivots(_ffi.make_params(N, T, K), mu, L, W)
+    np.testing.assert_allclose(got, np.expm1(T * np.log1p(m)), rtol=1e-14)
+    np.testing.assert_allclose(got, (1 + m) ** T - 1, rtol=1e-11)
+    s2 = np.einsum("ki,ij,kj->k", W.astype(np.float64), np.tril(L).astype(np.float64) @ np.tril(L).astype(np.float64).T, W.astype(np.float64))
+    got = _ffi.pivots(_ffi.make_params(N, T, K, "log"), mu, L, W)
+    np.testing.assert_allclose(got, np.expm1(T * (m + s2 / 2)), rtol=1e-12)
+    assert np.all(_ffi.pivots(_ffi.make_params(N, 0, K), mu, L, W) == 0)
+    wild = _ffi.pivots(_ffi.make_params(N, 10**6, 1), np.full(N, 5.0, np.float32), L, W[:1])      # overflows: falls back to 0
+    assert wild[0] == 0.0
 
 
 def test_pack_params_rejects_bad_shapes(mcp_lib):
@@ -128,15 +157,17 @@ def test_terminal_to_x(mcp_lib):
 def test_argument_errors_are_reported_not_thrown(mcp_lib):
     prm = _ffi.make_params(4, 10, 1)
     prm.n_assets = 0
-    assert mcp_lib.mcp_launch_paths(ctypes.byref(prm), None, 0, 0, 100, None, 100, None) == -1
+    assert mcp_lib.mcp_launch_paths(ctypes.byref(prm), None, None, 0, 0, 100, None, 100, None, None, None) == -1
     assert b"n_assets" in mcp_lib.mcp_last_error()
     prm = _ffi.make_params(4, 10, 1, alpha=0.95)
-    assert mcp_lib.mcp_launch_paths(ctypes.byref(prm), None, 0, 0, 100, None, 100, None) == -1
+    assert mcp_lib.mcp_launch_paths(ctypes.byref(prm), None, None, 0, 0, 100, None, 100, None, None, None) == -1
     assert b"NULL device pointer" in mcp_lib.mcp_last_error()
+    assert mcp_lib.mcp_launch_sum_u64(None, 2, 16, None) == -1 and mcp_lib.mcp_ctx_exchange_mode(None) == _ffi.EXCHANGE_UNSET
+    assert mcp_lib.mcp_ctx_exchange_note(None) == b""
     prm.alpha = 1.5
     assert mcp_lib.mcp_launch_stats(ctypes.byref(prm), 1, None, None, None, None) == -1 and b"alpha" in mcp_lib.mcp_last_error()
     prm.alpha = 0.95
-    assert mcp_lib.mcp_launch_scan(ctypes.byref(prm), 2, 10, 0, 1, None, None, None, None, None) == -1     # pass 2 is mcp_launch_final
+    assert mcp_lib.mcp_launch_scan(ctypes.byref(prm), 2, 10, 0, 1, None, None, None, None, None, None, None) == -1     # pass 2 is mcp_launch_final
     with pytest.raises(ValueError):
         _ffi.make_params(4, 10, 1, compounding="weird")
 
@@ -173,7 +204,8 @@ def test_header_is_valid_c99_and_links_from_c(tmp_path, mcp_lib):
             if (mcp_abi_version() != MCP_ABI_VERSION) return 1;
             if (mcp_percentile_rank(1000000, p.alpha, &lo, &hi, &g) != MCP_OK) return 2;
             if (mcp_packed_len(16, 1) != 16 + 16 * 9 + 8 * 16 + 20) return 3;
-            if (mcp_launch_paths(&p, NULL, 0, 0, 10, NULL, 10, NULL) != MCP_E_ARG) return 4;
+            if (mcp_launch_paths(&p, NULL, NULL, 0, 0, 10, NULL, 10, NULL, NULL, NULL) != MCP_E_ARG) return 4;
+            if (mcp_ws_bytes(MCP_WS_PARTIALS, 1, 1000000) != 3907 * 32 || mcp_moment_slots(17, 128) != 2) return 5;
             printf("%llu %llu %.17g %s\n", (unsigned long long)lo, (unsigned long long)hi, g, mcp_last_error());
             return 0;
         }''')

@@ -32,8 +32,9 @@ mu, cov = synthetic.synthetic_market(N)
 W = synthetic.dirichlet_weights(N, K) if K > 1 else synthetic.equal_weights(N)
 mu32, L, W32 = prepare_inputs(mu, cov, W)
 eng = PathEngine(mu32, L, W32, T, n_local, device="cpu", kernels=FakeKernels(mu32, L, W32), rf=0.002,
-                 group=dist.group.WORLD if world > 1 else None, world_size=world, rank=rank)
-eng.step(seed=77, path_base=1000)
+                 group=dist.group.WORLD if world > 1 else None, world_size=world, rank=rank, **{extra})
+for i in range({steps}):                      # the LAST step is the one compared (seed 77)
+    eng.step(seed=77 + {steps} - 1 - i, path_base=1000)
 st = eng.stats()
 out = [{{k: (int(st[i][k]) if k in ("n", "n_tail") else float(st[i][k]).hex()) for k in st.dtype.names}} for i in range(K)]
 open({out!r} + str(rank), "w").write(json.dumps(out))
@@ -50,10 +51,10 @@ def free_port():
     return p
 
 
-def run_world(tmp_path, world, N, T, n_local, K):
-    out = str(tmp_path / f"res_w{world}_")
-    script = tmp_path / f"worker_w{world}.py"
-    script.write_text(WORKER.format(root=ROOT, N=N, T=T, n_local=n_local, K=K, out=out))
+def run_world(tmp_path, world, N, T, n_local, K, steps=1, extra=None, tag=""):
+    out = str(tmp_path / f"res_w{world}{tag}_")
+    script = tmp_path / f"worker_w{world}{tag}.py"
+    script.write_text(WORKER.format(root=ROOT, N=N, T=T, n_local=n_local, K=K, out=out, steps=steps, extra=repr(extra or {})))
     port = free_port()
     procs = []
     for r in range(world):
@@ -91,6 +92,52 @@ def test_two_ranks_equal_one_rank_and_reference(tmp_path, K):
         for key in ("mean", "std", "sharpe", "cvar"):         # fp64 sums: association differs across ranks
             assert float.fromhex(a[key]) == pytest.approx(float.fromhex(b[key]), rel=1e-13)
             assert float.fromhex(a[key]) == pytest.approx(want[key], rel=1e-12)
+
+
+def test_skewed_schedule_two_ranks_many_steps(tmp_path):
+    """The software-pipelined enqueue order (stage s of batch t-s at step t, engine.py) over gloo: seven batches in flight
+    through six buffers, collectives of different batches interleaved; the last batch must equal the plain one-rank result."""
+    N, T, n_local, K = 8, 12, 1501, 2
+    skew = run_world(tmp_path, 2, N, T, n_local, K, steps=7, extra={"skew": True}, tag="s")
+    one = run_world(tmp_path, 1, N, T, 2 * n_local, K)
+    assert skew[0] == skew[1]
+    for k in range(K):
+        a, b = skew[0][k], one[0][k]
+        for key in ("n", "n_tail", "var", "x_lo", "x_hi", "min", "max"):
+            assert a[key] == b[key], key
+        for key in ("mean", "std", "sharpe", "cvar"):
+            assert float.fromhex(a[key]) == pytest.approx(float.fromhex(b[key]), rel=1e-13)
+
+
+@pytest.mark.parametrize("shards,skew", [(3, True), (2, False), (8, True)])
+def test_logical_shards_equal_one_shard(shards, skew):
+    """logical_shards: one process splits its path range over S shards that exchange through the sum kernel and record
+    copies (what a one-GPU box can run of the N > 1 choreography); equal to the unsharded engine, also for shards
+    without any path (8 shards of 5 paths)."""
+    import torch  # noqa: F401
+    from fake_kernels import FakeKernels
+    from monte_carlo_portfolio_amd import synthetic
+    from monte_carlo_portfolio_amd.engine import PathEngine
+    from monte_carlo_portfolio_amd.simulate import prepare_inputs
+    N, T, K = 6, 10, 3
+    n = 5 if shards == 8 else 2999
+    mu, cov = synthetic.synthetic_market(N)
+    mu32, L, W32 = prepare_inputs(mu, cov, synthetic.dirichlet_weights(N, K))
+    ref = PathEngine(mu32, L, W32, T, n, device="cpu", kernels=FakeKernels(mu32, L, W32), rf=0.001)
+    ref.step(seed=5)
+    want = ref.stats()
+    eng = PathEngine(mu32, L, W32, T, n, device="cpu", kernels=FakeKernels(mu32, L, W32), rf=0.001, logical_shards=shards, skew=skew)
+    for i in range(9):
+        eng.step(seed=5 + 8 - i)
+    got = eng.stats()
+    assert np.array_equal(eng.terminal(), ref.terminal())
+    for key in ("n", "n_tail", "var", "x_lo", "x_hi", "min", "max"):
+        assert np.array_equal(got[key], want[key]), key
+    for key in ("mean", "std", "sharpe", "cvar"):
+        np.testing.assert_allclose(got[key], want[key], rtol=1e-13)
+    eng.step(seed=5)                                     # the pipeline keeps working after a drain
+    again = eng.stats()
+    assert np.array_equal(again["var"], want["var"]) and np.array_equal(again["n_tail"], want["n_tail"])
 
 
 PF_WORKER = r"""

@@ -309,7 +309,7 @@ def test_pipelined_engine_batches_are_independent_and_correct(gpu_ctx):
     eng.synchronize()
     want = {s: simulate_paths(mu, cov, w, n_steps=T, n_paths=P, seed=s) for s in seeds[-2:]}
     for back, s in ((0, seeds[-1]), (1, seeds[-2])):       # the two batches still resident in the double buffer
-        b = eng.bufs[(eng.last - back) % eng.n_buf]
+        b = eng.bufs[(eng.last - back) % eng.n_buf][0]
         raw = b["ws"][_ffi.WS_STATS].cpu().numpy().view(np.uint8)[:_ffi.STATS_DTYPE.itemsize].view(_ffi.STATS_DTYPE)[0]
         for key in raw.dtype.names:
             assert raw[key] == want[s][key], (s, key)

@@ -28,8 +28,9 @@ def check_against_reference(got, terminal, v0=1.0, compounding="simple", alpha=0
 
 
 # ---------------------------------------------------------------- statistics pipeline on hand-made terminal values
-def stats_of_values(values, alpha=0.95, v0=1.0, compounding="simple", rf=0.0):
-    """Run pass0 -> scan -> hist -> scan -> hist -> final on caller-supplied terminal values (device-level ABI)."""
+def stats_of_values(values, alpha=0.95, v0=1.0, compounding="simple", rf=0.0, pivot=None):
+    """Run pass0 -> scan -> hist -> scan -> hist -> final on caller-supplied terminal values (device-level ABI).
+    `pivot`: the shift of the moment sums (None: the x of the first value, as a caller without a model would choose)."""
     import torch
     lib = _ffi.lib()
     v = np.ascontiguousarray(values, np.float32)
@@ -37,19 +38,23 @@ def stats_of_values(values, alpha=0.95, v0=1.0, compounding="simple", rf=0.0):
     prm = _ffi.make_params(4, 1, 1, compounding, v0, alpha, rf)
     dev = torch.device("cuda", 0)
     term = torch.from_numpy(v.reshape(1, n)).to(dev)
-    ws = [torch.zeros((lib.mcp_ws_bytes(w, 1) + 7) // 8, dtype=torch.int64, device=dev) for w in range(_ffi.WS_COUNT)]
+    ws = [torch.zeros((lib.mcp_ws_bytes(w, 1, n) + 7) // 8, dtype=torch.int64, device=dev) for w in range(_ffi.WS_COUNT)]
+    if pivot is None:
+        pivot = float(ref_stats.terminal_to_x(v[:1], v0, compounding)[0])
+    ws[_ffi.WS_PIVOT] = torch.tensor([pivot], dtype=torch.float64, device=dev)
     p = [ctypes.c_void_p(t.data_ptr()) for t in ws]
     lo, hi, g = _ffi.percentile_rank(n, alpha)
     st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     T = ctypes.c_void_p(term.data_ptr())
-    P, R, S, H, Q, O = (p[_ffi.WS_PARTIALS], p[_ffi.WS_RECORD], p[_ffi.WS_STATE], p[_ffi.WS_HIST], p[_ffi.WS_QUANT], p[_ffi.WS_STATS])
+    P, R, S, H, Q, O, B, C = (p[_ffi.WS_PARTIALS], p[_ffi.WS_RECORD], p[_ffi.WS_STATE], p[_ffi.WS_HIST], p[_ffi.WS_QUANT], p[_ffi.WS_STATS],
+                              p[_ffi.WS_BELOW], p[_ffi.WS_PIVOT])
     for rep in range(2):                              # twice on the same buffers: the steps must leave them reusable
-        _ffi.check(lib.mcp_launch_pass0(ctypes.byref(prm), T, n, n, P, H, st))
-        _ffi.check(lib.mcp_launch_scan(ctypes.byref(prm), 0, n, lo, hi, P, H, S, R, st))
-        _ffi.check(lib.mcp_launch_hist(ctypes.byref(prm), 1, T, n, n, S, P, H, st))
-        _ffi.check(lib.mcp_launch_scan(ctypes.byref(prm), 1, n, lo, hi, P, H, S, R, st))
-        _ffi.check(lib.mcp_launch_hist(ctypes.byref(prm), 2, T, n, n, S, P, H, st))
-        _ffi.check(lib.mcp_launch_final(ctypes.byref(prm), n, g, lo, hi, P, H, S, R, Q, O, st))
+        _ffi.check(lib.mcp_launch_pass0(ctypes.byref(prm), T, n, n, C, P, H, st))
+        _ffi.check(lib.mcp_launch_scan(ctypes.byref(prm), 0, n, lo, hi, P, B, C, H, S, R, st))
+        _ffi.check(lib.mcp_launch_hist(ctypes.byref(prm), 1, T, n, n, S, C, B, H, st))
+        _ffi.check(lib.mcp_launch_scan(ctypes.byref(prm), 1, n, lo, hi, P, B, C, H, S, R, st))
+        _ffi.check(lib.mcp_launch_hist(ctypes.byref(prm), 2, T, n, n, S, C, B, H, st))
+        _ffi.check(lib.mcp_launch_final(ctypes.byref(prm), n, g, lo, hi, B, H, S, R, Q, O, st))
     torch.cuda.synchronize()
     assert int(ws[_ffi.WS_HIST].abs().sum().item()) == 0          # read-and-clear protocol: histogram back to zero
     rec = ws[_ffi.WS_STATS].cpu().numpy().view(np.uint8)[:_ffi.STATS_DTYPE.itemsize].view(_ffi.STATS_DTYPE)[0]
@@ -87,11 +92,35 @@ def test_statistics_pipeline_on_adversarial_values(gpu_ctx, case, alpha):
         v = (1.0 + 0.2 * rng.standard_normal(3_000_017)).astype(np.float32)
     comp = "log" if case == "negative" else "simple"
     got = stats_of_values(v, alpha=alpha, compounding=comp, rf=0.01)
-    if case == "collapse_run":      # relative spread 1e-14: sum x^2 - sum x * mean cancels (std is not the point of this case)
-        want = ref_stats.path_stats(v, 1.0, comp, alpha, 0.01)
-        assert got["n_tail"] == want["n_tail"] and got["var"] == want["var"] and got["cvar"] == pytest.approx(want["cvar"], rel=1e-13)
-        return
+    # collapse_run included: x = -1 + O(1e-10) with a relative spread of 1e-14; the shifted moment sums keep its std
+    # (2.4e-14) where sum x^2 - sum x * mean returned 0 (round 2)
     check_against_reference(got, v, 1.0, comp, alpha, 0.01, exact_var=(comp == "simple"))
+
+
+@pytest.mark.parametrize("rel_sigma", [1e-3, 1e-5, 1e-7])
+@pytest.mark.parametrize("level", [1.07, 250.0, 0.004])
+def test_moments_of_a_low_volatility_portfolio(gpu_ctx, rel_sigma, level):
+    """sigma << |mean| (a hedged book): np.std(ddof=1) (app.py:234) is two-pass, and the raw-moment formula
+    sum x^2 - sum x * mean loses (mean/sigma)^2 * 1e-16 of the variance -- everything at sigma/|mean| = 1e-7.  The kernels
+    accumulate sum (x - c), sum (x - c)^2 around a pivot c: std and Sharpe to 1e-9 of the float64 two-pass values for any
+    pivot within a few sigma of the mean (here: the first value, and the exact mean), and no worse than the raw formula
+    for a pivot that is far off (0)."""
+    rng = np.random.default_rng(int(1 / rel_sigma) + int(level * 10))
+    v = (level * (1.0 + rel_sigma * rng.standard_normal(300_007))).astype(np.float32)
+    x = v.astype(np.float64) - 1.0
+    want = ref_stats.path_stats(v, 1.0, "simple", 0.95, 0.0)
+    assert want["std"] == pytest.approx(x.std(ddof=1), rel=1e-14)
+    for pivot in (None, float(x.mean())):
+        got = stats_of_values(v, pivot=pivot)
+        assert got["std"] == pytest.approx(want["std"], rel=1e-9), (pivot, got["std"], want["std"])
+        assert got["sharpe"] == pytest.approx(want["sharpe"], rel=1e-9)
+        assert got["mean"] == pytest.approx(want["mean"], rel=1e-14)
+        assert got["var"] == want["var"] and got["n_tail"] == want["n_tail"]
+        assert got["cvar"] == pytest.approx(want["cvar"], rel=1e-12)
+    got = stats_of_values(v, pivot=0.0)                          # raw sums: what round 2 computed; accuracy (mean/sigma)^2 * 1e-16
+    loss = (want["mean"] / want["std"]) ** 2 * 2e-16
+    if loss < 0.1:
+        assert got["std"] == pytest.approx(want["std"], rel=max(20 * loss, 1e-12))
 
 
 @pytest.mark.parametrize("K,n", [(2000, 1000), (1100, 4096), (37, 70_001)])
@@ -105,22 +134,31 @@ def test_statistics_pipeline_many_portfolios_at_once(gpu_ctx, K, n):
     prm = _ffi.make_params(4, 1, K)
     dev = torch.device("cuda", 0)
     term = torch.from_numpy(v).to(dev)
-    ws = [torch.zeros((lib.mcp_ws_bytes(w, K) + 7) // 8, dtype=torch.int64, device=dev) for w in range(_ffi.WS_COUNT)]
+    ws = [torch.zeros((lib.mcp_ws_bytes(w, K, n) + 7) // 8, dtype=torch.int64, device=dev) for w in range(_ffi.WS_COUNT)]
+    ws[_ffi.WS_PIVOT] = torch.from_numpy(v[:, 0].astype(np.float64) - 1.0).to(dev)
     p = [ctypes.c_void_p(t.data_ptr()) for t in ws]
     lo, hi, g = _ffi.percentile_rank(n, 0.95)
     st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     T, B = ctypes.c_void_p(term.data_ptr()), ctypes.byref(prm)
-    P, R, S, H, Q, O = (p[_ffi.WS_PARTIALS], p[_ffi.WS_RECORD], p[_ffi.WS_STATE], p[_ffi.WS_HIST], p[_ffi.WS_QUANT], p[_ffi.WS_STATS])
+    P, R, S, H, Q, O, BL, C = (p[_ffi.WS_PARTIALS], p[_ffi.WS_RECORD], p[_ffi.WS_STATE], p[_ffi.WS_HIST], p[_ffi.WS_QUANT], p[_ffi.WS_STATS],
+                               p[_ffi.WS_BELOW], p[_ffi.WS_PIVOT])
     x = v.astype(np.float64) - 1.0
     want_var = np.percentile(x, (1 - 0.95) * 100, axis=1)
     first = None
     for rep in range(3):
-        _ffi.check(lib.mcp_launch_pass0(B, T, n, n, P, H, st))
-        _ffi.check(lib.mcp_launch_scan(B, 0, n, lo, hi, P, H, S, R, st))
-        _ffi.check(lib.mcp_launch_hist(B, 1, T, n, n, S, P, H, st))
-        _ffi.check(lib.mcp_launch_scan(B, 1, n, lo, hi, P, H, S, R, st))
-        _ffi.check(lib.mcp_launch_hist(B, 2, T, n, n, S, P, H, st))
-        _ffi.check(lib.mcp_launch_final(B, n, g, lo, hi, P, H, S, R, Q, O, st))
+        if rep == 1 and K >= 17:                      # the lean digit-0 pass of the sweep path must agree with pass 0's own histogram
+            _ffi.check(lib.mcp_launch_hist(B, 0, T, n, n, None, C, None, H, st))
+            h_lean = ws[_ffi.WS_HIST].clone()
+            ws[_ffi.WS_HIST].zero_()
+            _ffi.check(lib.mcp_launch_pass0(B, T, n, n, C, P, H, st))
+            assert torch.equal(h_lean, ws[_ffi.WS_HIST])
+        else:
+            _ffi.check(lib.mcp_launch_pass0(B, T, n, n, C, P, H, st))
+        _ffi.check(lib.mcp_launch_scan(B, 0, n, lo, hi, P, BL, C, H, S, R, st))
+        _ffi.check(lib.mcp_launch_hist(B, 1, T, n, n, S, C, BL, H, st))
+        _ffi.check(lib.mcp_launch_scan(B, 1, n, lo, hi, P, BL, C, H, S, R, st))
+        _ffi.check(lib.mcp_launch_hist(B, 2, T, n, n, S, C, BL, H, st))
+        _ffi.check(lib.mcp_launch_final(B, n, g, lo, hi, BL, H, S, R, Q, O, st))
         torch.cuda.synchronize()
         rec = ws[_ffi.WS_STATS].cpu().numpy().view(np.uint8)[:K * _ffi.STATS_DTYPE.itemsize].view(_ffi.STATS_DTYPE).copy()
         assert np.array_equal(rec["var"], want_var)

@@ -21,7 +21,7 @@ def build(specs):
         print(name, "ok" if r.returncode == 0 else "FAILED\n" + r.stdout[-2000:] + r.stderr[-2000:])
 
 
-def run(names, paths, rounds, assets, steps, native):
+def run(names, paths, rounds, assets, steps, native, stats=True):
     import numpy as np, torch
     from monte_carlo_portfolio_amd import _ffi, synthetic
     from monte_carlo_portfolio_amd.simulate import prepare_inputs
@@ -31,6 +31,9 @@ def run(names, paths, rounds, assets, steps, native):
     prm = _ffi.make_params(assets, steps, 1, native_math=native)
     packed = torch.from_numpy(_ffi.pack_params(mu32, L, W32)).cuda()
     term = torch.empty((1, paths), dtype=torch.float32, device="cuda")
+    pivot = torch.from_numpy(_ffi.pivots(prm, mu32, L, W32)).cuda()
+    partials = torch.zeros(base.mcp_ws_bytes(_ffi.WS_PARTIALS, 1, paths) // 8, dtype=torch.int64, device="cuda")
+    hist = torch.zeros(base.mcp_ws_bytes(_ffi.WS_HIST, 1, paths) // 8, dtype=torch.int64, device="cuda")
     libs = {}
     for n in names:
         path = _ffi.LIB_PATH if n == "base" else os.path.join(LAB, f"libmcport_{n}.so")
@@ -41,8 +44,11 @@ def run(names, paths, rounds, assets, steps, native):
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def launch(Lb):
-        rc = Lb.mcp_launch_paths(ctypes.byref(prm), ctypes.c_void_p(packed.data_ptr()), synthetic.BENCH_SEED, 0, paths,
-                                 ctypes.c_void_p(term.data_ptr()), paths, stream)
+        if stats:
+            hist.zero_()
+        rc = Lb.mcp_launch_paths(ctypes.byref(prm), ctypes.c_void_p(packed.data_ptr()), ctypes.c_void_p(pivot.data_ptr()),
+                                 synthetic.BENCH_SEED, 0, paths, ctypes.c_void_p(term.data_ptr()), paths,
+                                 ctypes.c_void_p(partials.data_ptr()) if stats else None, ctypes.c_void_p(hist.data_ptr()) if stats else None, stream)
         assert rc == 0, rc
 
     ref = None
@@ -73,5 +79,6 @@ if __name__ == "__main__":
         ap.add_argument("--paths", type=int, default=1_000_000); ap.add_argument("--rounds", type=int, default=10)
         ap.add_argument("--assets", type=int, default=16); ap.add_argument("--steps", type=int, default=252)
         ap.add_argument("--native", action="store_true")
+        ap.add_argument("--no-stats", action="store_true", help="terminal values only (no fused statistics epilogue)")
         a = ap.parse_args()
-        run(a.names, a.paths, a.rounds, a.assets, a.steps, a.native)
+        run(a.names, a.paths, a.rounds, a.assets, a.steps, a.native, not a.no_stats)

@@ -1,0 +1,135 @@
+// mfma_coexec.hip -- does non-fp32 work hide in the shadow of an fp32 MFMA on gfx950?
+//
+// Question (VERDICT r2, configs[3]): in the N = 64 path kernel half of a step's issue cycles are integer / bit / LDS work
+// (16 Philox blocks, 64 table transforms).  If v_mad_u64_u32 / v_bitop3_b32 / ds_read_b128 issue while a
+// v_mfma_f32_32x32x2_f32 (64 cycles per SIMD) or v_mfma_f32_16x16x4_f32 (32) is in flight, casting r = mu + L z as MFMA tiles
+// would overlap the GEMV with the next step's draw (cost ~ max); if the matrix instruction holds the SIMD's issue port, or
+// runs on the same lanes as the VALU, the cost is the sum and the cast buys nothing.  round 1 measured fp32 FMA fillers
+// (sum); this measures the fillers that matter.
+//
+// One loop iteration = 8 MFMAs, with NF fillers of one kind after each MFMA (independent of it and of each other in groups
+// of 8 chains).  Reported per configuration: shader cycles per iteration (s_memtime), for MFMA alone, fillers alone
+// (the same instruction stream with the MFMAs removed) and both; "hidden" = 1 - (both - max(alone)) / min(alone):
+// 1 = perfectly overlapped, 0 = purely additive.  1, 2 and 4 waves per SIMD.
+// Counters: rocprofv3 --pmc SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_BUSY_CYCLES -- ./mfma_coexec
+// (one dispatch per configuration; kernel names carry the template arguments).
+// Build: hipcc -O3 --offload-arch=gfx950 mfma_coexec.hip -o mfma_coexec
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int ITERS = 1024;
+enum { F_NONE = 0, F_FMA = 1, F_MAD64 = 2, F_BITOP3 = 3, F_DSREAD = 4, F_PKFMA = 5, F_PHILOXMIX = 6 };
+
+// MF: 0 = no MFMA (fillers alone), 1 = v_mfma_f32_32x32x2_f32, 2 = v_mfma_f32_16x16x4_f32
+template <int MF, int FILL, int NF>
+__global__ void __launch_bounds__(1024) coexec(float* out, unsigned long long* cyc, float seedf, unsigned seedu) {
+  float v[8]; unsigned u[8]; unsigned long long w[8]; f32x2 p[8]; f32x4 ld[8];
+  for (int i = 0; i < 8; i++) {
+    v[i] = seedf + 0.001f * (threadIdx.x + i); u[i] = seedu * (threadIdx.x + 7 * i + 1); w[i] = u[i];
+    p[i] = f32x2{v[i], v[i] + 1.f}; ld[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float ca = seedf * 0.5f, cb = 0.25f; unsigned cu = seedu | 1u, ck = seedu ^ 0x5bd1e995u;
+  asm volatile("" : "+v"(ca), "+v"(cb), "+v"(cu), "+v"(ck));
+  __shared__ f32x4 ldsbuf[1056];
+  for (int i = threadIdx.x; i < 1056; i += blockDim.x) ldsbuf[i] = f32x4{seedf + i, ca, cb, 1.f};
+  __syncthreads();
+  unsigned ldsaddr = (unsigned)(size_t)(&ldsbuf[0]) + ((threadIdx.x * 37u) % 1024u) * 16u;     // scattered 16-byte reads, like the table
+  f32x16 acc32[2]; f32x4 acc16[4];
+  for (int i = 0; i < 16; i++) { acc32[0][i] = seedf; acc32[1][i] = cb; }
+  for (int i = 0; i < 4; i++) acc16[i] = f32x4{seedf, cb, ca, 1.f};
+  float ma = v[0], mb = v[1];
+
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+  for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      if constexpr (MF == 1) acc32[m & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ma, mb, acc32[m & 1], 0, 0, 0);
+      if constexpr (MF == 2) acc16[m & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ma, mb, acc16[m & 3], 0, 0, 0);
+#pragma unroll
+      for (int f = 0; f < NF; f++) {
+        const int i = (m * NF + f) & 7;
+        if constexpr (FILL == F_FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[i]) : "v"(ca), "v"(cb));
+        if constexpr (FILL == F_MAD64) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(u[i]), "v"(cu) : "vcc");
+        if constexpr (FILL == F_BITOP3) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(u[i]) : "v"(ck), "v"(cu));
+        if constexpr (FILL == F_DSREAD) asm volatile("ds_read_b128 %0, %1" : "=v"(ld[i]) : "v"(ldsaddr));
+        if constexpr (FILL == F_PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));
+        if constexpr (FILL == F_PHILOXMIX) {      // the Philox round's own mix: one widening multiply, one three-input xor
+          if (f & 1) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(u[i]) : "v"(ck), "v"(cu));
+          else asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(w[i]) : "v"(u[i]), "v"(cu) : "vcc");
+        }
+      }
+    }
+    if constexpr (FILL == F_DSREAD) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f; unsigned su = 0;
+  for (int i = 0; i < 8; i++) { s += v[i] + p[i].x + p[i].y + ld[i].x + ld[i].w; su ^= u[i] ^ (unsigned)w[i] ^ (unsigned)(w[i] >> 32); }
+  for (int i = 0; i < 16; i++) s += acc32[0][i] + acc32[1][i];
+  for (int i = 0; i < 4; i++) s += acc16[i].x + acc16[i].y + acc16[i].z + acc16[i].w;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)su;
+  if (threadIdx.x == 0) { cyc[2 * blockIdx.x] = t1 - t0; cyc[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+struct Result { double cycles_per_iter, ghz; };
+
+template <int MF, int FILL, int NF>
+Result run(int wps, float* d_out, unsigned long long* d_cyc, int num_cu) {
+  const int blocks = num_cu;                            // ONE workgroup of 4 wps waves per CU: wps waves co-resident on every SIMD
+  coexec<MF, FILL, NF><<<blocks, 256 * wps>>>(d_out, d_cyc, 1.0001f, 0x9E3779B9u);
+  CHECK(hipDeviceSynchronize());
+  coexec<MF, FILL, NF><<<blocks, 256 * wps>>>(d_out, d_cyc, 1.0001f, 0x9E3779B9u);
+  CHECK(hipDeviceSynchronize());
+  std::vector<unsigned long long> h(2 * blocks);
+  CHECK(hipMemcpy(h.data(), d_cyc, 2 * blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::vector<double> c(blocks), g(blocks);
+  for (int b = 0; b < blocks; b++) { c[b] = (double)h[2 * b] / ITERS; g[b] = (double)h[2 * b] / (double)h[2 * b + 1] * 0.1; }
+  std::sort(c.begin(), c.end()); std::sort(g.begin(), g.end());
+  return {c[blocks / 2], g[blocks / 2]};
+}
+
+template <int MF, int FILL, int NF>
+void report(const char* mf_name, const char* fill_name, float* d_out, unsigned long long* d_cyc, int num_cu) {
+  for (int wps : {1, 2, 4}) {
+    const Result m = run<MF, F_NONE, 0>(wps, d_out, d_cyc, num_cu);
+    const Result f = run<0, FILL, NF>(wps, d_out, d_cyc, num_cu);
+    const Result b = run<MF, FILL, NF>(wps, d_out, d_cyc, num_cu);
+    const double mx = std::max(m.cycles_per_iter, f.cycles_per_iter), mn = std::min(m.cycles_per_iter, f.cycles_per_iter);
+    printf("%-24s + %2d x %-14s waves/SIMD=%d  cycles/iter (8 MFMA): mfma %7.1f  fill %7.1f  both %7.1f  sum %7.1f  max %7.1f  hidden %5.2f  clk %.2f GHz\n",
+           mf_name, NF, fill_name, wps, m.cycles_per_iter, f.cycles_per_iter, b.cycles_per_iter, m.cycles_per_iter + f.cycles_per_iter, mx,
+           1.0 - (b.cycles_per_iter - mx) / mn, b.ghz);
+  }
+}
+
+int main() {
+  hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+  const int num_cu = prop.multiProcessorCount;
+  printf("device %s  CUs=%d  (cycles are wave-lifetime shader cycles per loop iteration of ONE wave; at w waves/SIMD the SIMD "
+         "spends cycles/w per iteration)\n", prop.gcnArchName, num_cu);
+  float* d_out; unsigned long long* d_cyc;
+  CHECK(hipMalloc(&d_out, (size_t)num_cu * 1024 * sizeof(float)));
+  CHECK(hipMalloc(&d_cyc, (size_t)num_cu * 4 * 2 * sizeof(unsigned long long)));
+#define ROWS(MF, NAME)                                                            \
+  report<MF, F_FMA, 8>(NAME, "v_fma_f32", d_out, d_cyc, num_cu);                  \
+  report<MF, F_PKFMA, 8>(NAME, "v_pk_fma_f32", d_out, d_cyc, num_cu);             \
+  report<MF, F_MAD64, 8>(NAME, "v_mad_u64_u32", d_out, d_cyc, num_cu);            \
+  report<MF, F_BITOP3, 8>(NAME, "v_bitop3_b32", d_out, d_cyc, num_cu);            \
+  report<MF, F_PHILOXMIX, 8>(NAME, "mad64+bitop3", d_out, d_cyc, num_cu);         \
+  report<MF, F_PHILOXMIX, 12>(NAME, "mad64+bitop3", d_out, d_cyc, num_cu);        \
+  report<MF, F_DSREAD, 4>(NAME, "ds_read_b128", d_out, d_cyc, num_cu);
+  ROWS(1, "v_mfma_f32_32x32x2_f32")
+  ROWS(2, "v_mfma_f32_16x16x4_f32")
+  return 0;
+}

@@ -18,17 +18,19 @@ while time.time() < t_end:
     v = (1.0 + 0.05 * rng.standard_normal((K, n))).astype(np.float32)
     prm = _ffi.make_params(4, 1, K)
     term = torch.from_numpy(v).cuda()
-    ws = [torch.zeros((lib.mcp_ws_bytes(w, K) + 7) // 8, dtype=torch.int64, device="cuda") for w in range(_ffi.WS_COUNT)]
+    ws = [torch.zeros((lib.mcp_ws_bytes(w, K, n) + 7) // 8, dtype=torch.int64, device="cuda") for w in range(_ffi.WS_COUNT)]
+    ws[_ffi.WS_PIVOT] = torch.from_numpy(v[:, 0].astype(np.float64) - 1.0).cuda()
     p = [ctypes.c_void_p(t.data_ptr()) for t in ws]
     lo, hi, g = _ffi.percentile_rank(n, 0.95)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     T, B = ctypes.c_void_p(term.data_ptr()), ctypes.byref(prm)
-    P, R, S, H, Q, O = (p[_ffi.WS_PARTIALS], p[_ffi.WS_RECORD], p[_ffi.WS_STATE], p[_ffi.WS_HIST], p[_ffi.WS_QUANT], p[_ffi.WS_STATS])
+    P, R, S, H, Q, O, BL, C = (p[_ffi.WS_PARTIALS], p[_ffi.WS_RECORD], p[_ffi.WS_STATE], p[_ffi.WS_HIST], p[_ffi.WS_QUANT], p[_ffi.WS_STATS],
+                               p[_ffi.WS_BELOW], p[_ffi.WS_PIVOT])
     want = np.percentile(v.astype(np.float64) - 1.0, 5.000000000000004, axis=1)
     for rep in range(20):
-        lib.mcp_launch_pass0(B, T, n, n, P, H, st); lib.mcp_launch_scan(B, 0, n, lo, hi, P, H, S, R, st)
-        lib.mcp_launch_hist(B, 1, T, n, n, S, P, H, st); lib.mcp_launch_scan(B, 1, n, lo, hi, P, H, S, R, st)
-        lib.mcp_launch_hist(B, 2, T, n, n, S, P, H, st); lib.mcp_launch_final(B, n, g, lo, hi, P, H, S, R, Q, O, st)
+        lib.mcp_launch_pass0(B, T, n, n, C, P, H, st); lib.mcp_launch_scan(B, 0, n, lo, hi, P, BL, C, H, S, R, st)
+        lib.mcp_launch_hist(B, 1, T, n, n, S, C, BL, H, st); lib.mcp_launch_scan(B, 1, n, lo, hi, P, BL, C, H, S, R, st)
+        lib.mcp_launch_hist(B, 2, T, n, n, S, C, BL, H, st); lib.mcp_launch_final(B, n, g, lo, hi, BL, H, S, R, Q, O, st)
         torch.cuda.synchronize()
         rec = ws[_ffi.WS_STATS].cpu().numpy().view(np.uint8)[:K * _ffi.STATS_DTYPE.itemsize].view(_ffi.STATS_DTYPE)
         bad += int((rec["var"] != want).sum()); reps += 1
@@ -52,7 +54,7 @@ for nb in (2, 4):
         steps += 200
         eng.synchronize()
         for back in range(nb):                      # the nb most recent batches are still resident
-            b = eng.bufs[(eng.last - back) % eng.n_buf]
+            b = eng.bufs[(eng.last - back) % eng.n_buf][0]
             raw = b["ws"][_ffi.WS_STATS].cpu().numpy().view(np.uint8)[:_ffi.STATS_DTYPE.itemsize].view(_ffi.STATS_DTYPE)[0]
             s = hist[-1 - back]
             wrong += int(any(raw[k] != want[s][k] for k in raw.dtype.names))
