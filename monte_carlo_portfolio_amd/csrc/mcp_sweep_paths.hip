@@ -27,14 +27,59 @@ namespace mcp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- lane exchanges of the fused moment reduction (no LDS round trip: DPP inside a 16-lane row, v_permlane16_swap across) ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, true);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+constexpr int DPP_XOR1 = 0xB1;           // quad_perm:[1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;           // quad_perm:[2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;   // lane i <-> 7 - i inside each group of 8
+constexpr int DPP_MIRROR = 0x140;        // lane i <-> 15 - i inside the row
+// sum / min / max over the 16 lanes of each row, the same value in every lane; fixed order (deterministic)
+__device__ __forceinline__ double row_sum(double v) {
+  v += dpp_f64<DPP_XOR1>(v); v += dpp_f64<DPP_XOR2>(v); v += dpp_f64<DPP_HALF_MIRROR>(v); v += dpp_f64<DPP_MIRROR>(v);
+  return v;
+}
+__device__ __forceinline__ float row_min(float v) {
+  v = fminf(v, dpp_f32<DPP_XOR1>(v)); v = fminf(v, dpp_f32<DPP_XOR2>(v)); v = fminf(v, dpp_f32<DPP_HALF_MIRROR>(v)); v = fminf(v, dpp_f32<DPP_MIRROR>(v));
+  return v;
+}
+__device__ __forceinline__ float row_max(float v) {
+  v = fmaxf(v, dpp_f32<DPP_XOR1>(v)); v = fmaxf(v, dpp_f32<DPP_XOR2>(v)); v = fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_f32<DPP_MIRROR>(v));
+  return v;
+}
+// a, b: two values per lane.  v_permlane16_swap exchanges the odd rows of a with the even rows of b; afterwards a + b (min, max)
+// is, in the lanes of an EVEN row, the combination of the two a of lane l and lane l + 16, and in the lanes of an ODD row that of
+// the two b: the first step of two butterflies at once, without a select.
+__device__ __forceinline__ void swap16_f32(float& a, float& b) {
+  const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(sw[0]); b = __uint_as_float(sw[1]);
+}
+__device__ __forceinline__ void swap16_f64(double& a, double& b) {
+  const uint64_t ba = (uint64_t)__double_as_longlong(a), bb = (uint64_t)__double_as_longlong(b);
+  const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)ba, (uint32_t)bb, false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((uint32_t)(ba >> 32), (uint32_t)(bb >> 32), false, false);
+  a = __longlong_as_double((long long)(((uint64_t)hi[0] << 32) | lo[0]));
+  b = __longlong_as_double((long long)(((uint64_t)hi[1] << 32) | lo[1]));
+}
+
 // Fused moments of the sweep kernels (N3): the wave holds V for 32 MT portfolios x 64 paths in the MFMA C/D layout (lane l,
 // register g of tile (mt, nt): portfolio k_base + 32 mt + (g&3) + 8 (g>>2) + 4 (l>>5), path path0 + 32 nt + (l&31)).  Per
-// portfolio: x = V/v0 - 1 (or expm1 S), d = x - c_k, {sum d, sum d^2, min V, max V} over the wave's 64 paths -- the two
-// path tiles in the lane, then a shuffle reduction over the 32 lanes of the half-wave -- and ONE MomentPartial per portfolio
-// and wave tile, slot `tile` (= global 64-path tile index).  Dead paths (>= n_paths) contribute nothing.
+// portfolio: x = V/v0 - 1 (or expm1 S), d = x - c_k, {sum d, sum d^2, min V, max V} over the wave's 64 paths -- the two path
+// tiles in the lane, then over the 32 lanes of the half-wave: registers g and g + 8 are reduced together (swap16: lanes of
+// even rows end up with g, lanes of odd rows with g + 8), then four DPP steps inside the 16-lane row -- and ONE MomentPartial
+// per portfolio and wave tile, slot `tile` (= global 64-path tile index).  Dead paths (>= n_paths) contribute nothing.
 template <int MT, bool LOGC>
 __device__ __forceinline__ void sweep_moments(const PathArgs& a, const f32x16 (&V)[MT][2], int k_base, uint64_t path0) {
-  const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+  const int lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5, odd_row = (lane >> 4) & 1;
   if (path0 >= a.n_paths) return;                          // wave-uniform: a wave tile beyond the range has no slot
   const bool live0 = path0 + col < a.n_paths, live1 = path0 + 32 + col < a.n_paths;
   const uint64_t left = a.n_paths - path0;
@@ -44,30 +89,33 @@ __device__ __forceinline__ void sweep_moments(const PathArgs& a, const f32x16 (&
 #pragma unroll
   for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
-    for (int g = 0; g < 16; g++) {
-      const int k = k_base + 32 * mt + (g & 3) + 8 * (g >> 2) + 4 * half;
-      const bool mine = k < a.n_portfolios;                // rows beyond K are zero-weight padding
-      const double c = (mine && a.pivot) ? a.pivot[k] : 0.0;
-      const float v0 = V[mt][0][g], v1 = V[mt][1][g];
-      double x0, x1;
-      if constexpr (LOGC) { x0 = expm1((double)v0); x1 = expm1((double)v1); }
-      else if (a.v0_pow2) { x0 = __builtin_fma((double)v0, a.inv_v0d, -1.0); x1 = __builtin_fma((double)v1, a.inv_v0d, -1.0); }
-      else { x0 = (double)v0 / a.v0d - 1.0; x1 = (double)v1 / a.v0d - 1.0; }
-      const double d0 = live0 ? x0 - c : 0.0, d1 = live1 ? x1 - c : 0.0;
-      double s1 = d0 + d1;
-      double s2 = __builtin_fma(d0, d0, d1 * d1);
-      float mn = fminf(live0 ? v0 : inf, live1 ? v1 : inf);
-      float mx = fmaxf(live0 ? v0 : -inf, live1 ? v1 : -inf);
+    for (int gp = 0; gp < 8; gp++) {
+      double s1[2], s2[2];
+      float mn[2], mx[2];
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {                   // xor offsets < 32 stay inside the half-wave
-        s1 += __shfl_xor(s1, o, 64);
-        s2 += __shfl_xor(s2, o, 64);
-        mn = fminf(mn, __shfl_xor(mn, o, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      for (int h = 0; h < 2; h++) {
+        const int g = gp + 8 * h;
+        const int k = k_base + 32 * mt + (g & 3) + 8 * (g >> 2) + 4 * half;
+        const double c = (k < a.n_portfolios && a.pivot) ? a.pivot[k] : 0.0;      // rows beyond K are zero-weight padding
+        const float v0 = V[mt][0][g], v1 = V[mt][1][g];
+        double x0, x1;
+        if constexpr (LOGC) { x0 = expm1((double)v0); x1 = expm1((double)v1); }
+        else if (a.v0_pow2) { x0 = __builtin_fma((double)v0, a.inv_v0d, -1.0); x1 = __builtin_fma((double)v1, a.inv_v0d, -1.0); }
+        else { x0 = (double)v0 / a.v0d - 1.0; x1 = (double)v1 / a.v0d - 1.0; }
+        const double d0 = live0 ? x0 - c : 0.0, d1 = live1 ? x1 - c : 0.0;
+        s1[h] = d0 + d1;
+        s2[h] = __builtin_fma(d0, d0, d1 * d1);
+        mn[h] = fminf(live0 ? v0 : inf, live1 ? v1 : inf);
+        mx[h] = fmaxf(live0 ? v0 : -inf, live1 ? v1 : -inf);
       }
-      if (col == 0 && mine) {
+      swap16_f64(s1[0], s1[1]); swap16_f64(s2[0], s2[1]); swap16_f32(mn[0], mn[1]); swap16_f32(mx[0], mx[1]);
+      const double r1 = row_sum(s1[0] + s1[1]), r2 = row_sum(s2[0] + s2[1]);
+      const float rmn = row_min(fminf(mn[0], mn[1])), rmx = row_max(fmaxf(mx[0], mx[1]));
+      const int g = gp + 8 * odd_row;                      // what this row reduced
+      const int k = k_base + 32 * mt + (g & 3) + 8 * (g >> 2) + 4 * half;
+      if ((lane & 15) == 0 && k < a.n_portfolios) {
         MomentPartial m;
-        m.s1 = s1; m.s2 = s2; m.vmin = mn; m.vmax = mx; m.n = n_tile;
+        m.s1 = r1; m.s2 = r2; m.vmin = rmn; m.vmax = rmx; m.n = n_tile;
         a.partials[(size_t)k * a.slots + tile] = m;
       }
     }
