@@ -231,6 +231,13 @@ int mcp_launch_stats(const mcp_params *prm, int world, const void *d_gathered, c
  * all-reduce; the caller orders it after the producers and before the consumers of every buffer (events). */
 int mcp_launch_sum_u64(void *const *d_bufs, int n_bufs, size_t words, void *stream);
 
+/* A stream of `device` whose kernels may run on all but `reserve_cus` compute units (hipExtStreamCreateWithCUMask; the
+ * reserved ones are the highest-numbered CUs of the mask).  For hosts that pipeline batches: path kernels on such streams
+ * leave a few CUs to the small statistics / exchange kernels of the batch before, which otherwise queue for wave slots
+ * beside a kernel that fills the chip.  reserve_cus = 0: an ordinary non-blocking stream. */
+int mcp_stream_create(int device, int reserve_cus, void **stream_out);
+int mcp_stream_destroy(void *stream);
+
 /* The normal generator on its own: d_z[i] = inverse-CDF normal (SPEC.md section 3) of the 32-bit word d_x[i]. */
 int mcp_launch_normals(const uint32_t *d_x, uint64_t n, float *d_z, void *stream);
 

@@ -103,6 +103,8 @@ SIGNATURES = {
     "mcp_launch_final": (_int, [_PP, _u64, ctypes.c_double, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mcp_launch_stats": (_int, [_PP, _int, _vp, _vp, _vp, _vp]),
     "mcp_launch_sum_u64": (_int, [ctypes.POINTER(_vp), _int, ctypes.c_size_t, _vp]),
+    "mcp_stream_create": (_int, [_int, _int, ctypes.POINTER(_vp)]),
+    "mcp_stream_destroy": (_int, [_vp]),
     "mcp_launch_normals": (_int, [_vp, _u64, _vp, _vp]),
     "mcp_icdf_table": (_int, [_f32p, ctypes.c_size_t]),
     "mcp_float_to_key": (ctypes.c_uint32, [ctypes.c_float]),

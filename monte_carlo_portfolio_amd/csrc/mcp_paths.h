@@ -25,6 +25,9 @@
 #define MCP_MIN_WAVES 6     // __launch_bounds__ 2nd argument for N <= 16, one portfolio: at least 6 waves/SIMD (the kernel needs 74
                             // VGPRs; forced into 72 for 7 waves it spills 24 B per lane outside the loop and is 0.5 % slower)
 #endif
+#ifndef MCP_MIN_WAVES_BIG
+#define MCP_MIN_WAVES_BIG 1 // the same for 16 < N <= 64, one portfolio (experiment: 4 forces <= 128 VGPRs)
+#endif
 #ifndef MCP_EXP_VKEYS
 #define MCP_EXP_VKEYS 1
 #endif
@@ -112,7 +115,8 @@ constexpr int PATH_BLOCK = 256;
 // v = L^T w precomputed on the host (SPEC.md 4.1, one portfolio) instead of the triangular GEMV.
 // LOGC: compounding mode at compile time (as a run-time flag the compiler if-converts the step into fma + add + select).
 template <int NB, int KT, int PPT, bool NATIVE, bool FOLD = false, bool LOGC = false>
-__global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ? MCP_MIN_WAVES : 1) mc_paths_kernel(const PathArgs a) {
+__global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ? MCP_MIN_WAVES : ((KT == 1 && PPT == 1) ? MCP_MIN_WAVES_BIG : 1))
+mc_paths_kernel(const PathArgs a) {
   constexpr int N4 = 4 * NB;
   // wave-uniform parameters through the constant address space -> s_load_dword* into SGPRs
   typedef const __attribute__((address_space(4))) float* cfloat_p;
@@ -194,6 +198,9 @@ __global__ void __launch_bounds__(PATH_BLOCK, (NB <= 4 && KT == 1 && PPT == 1) ?
           philox4x32_10(blk, 0u, plo[e], phi[e], ks, x);
           block_normals<NATIVE>(x, s_tab, kc, z[e][0 * NB + q], z[e][1 * NB + q], z[e][2 * NB + q], z[e][3 * NB + q]);
         }
+#ifdef MCP_EXP_BLOCK_FENCE
+        if constexpr (NB > 4) __builtin_amdgcn_sched_barrier(0);   // experiment: one Philox block at a time (register pressure at N > 16)
+#endif
       }
       float rho[PPT][KT];
       if constexpr (FOLD) {

@@ -19,7 +19,7 @@ counter carries the *global* path id, so any partition yields the same terminal 
 {n, sum (x-c), sum (x-c)^2, min, max, below, pivot} (64 B per portfolio), merged in rank order by the statistics kernel.
 All are latency-bound; xGMI bandwidth is irrelevant at these sizes.
 
-Skewed schedule.  Every stage is a handful of tiny kernels that must find a free wave slot beside the path kernel of
+Skewed schedule (opt-in, `skew=True`).  Every stage is a handful of tiny kernels that must find a free wave slot beside the path kernel of
 the NEXT batch, which saturates the chip: run back to back, each of them (and each collective, which is a kernel too)
 waits for a slot, and the chain of one batch can take longer than the path kernel it hides behind.  So with exchanges
 in the chain the engine enqueues stage s of batch t-s at step t (a software pipeline, `depth` batches deep): by the time
@@ -103,7 +103,8 @@ class PathEngine:
 
     def __init__(self, mu32, chol32, W32, n_steps, n_paths_local, *, compounding="simple", v0=1.0, alpha=0.95,
                  rf=0.0, native_math=False, device=None, group=None, world_size=1, rank=0, kernels=None,
-                 pipeline=True, shard="paths", n_buffers=None, fold=False, logical_shards=1, skew=None, fused=True):
+                 pipeline=True, shard="paths", n_buffers=None, fold=False, logical_shards=1, skew=None, fused=True, cu_reserve=0,
+                 n_stats_streams=None):
         import torch
 
         self.torch = torch
@@ -144,9 +145,20 @@ class PathEngine:
         self.rank_lo, self.rank_hi, self.gamma = _ffi.percentile_rank(self.n_total, alpha)
         self.pipeline = bool(pipeline) and self.device.type == "cuda"
         self.exchanging = self.group is not None or self.S > 1
-        # skewed schedule (module docstring): on by default where the tail carries exchanges and batches are pipelined
-        # (it is a property of the enqueue ORDER: it also runs without streams, which is how the CPU tests cover it)
-        self.skew = (self.exchanging and self.pipeline) if skew is None else bool(skew)
+        # skewed schedule (module docstring): default where a torch process group carries the exchanges (its collectives run on
+        # ONE internal stream in issue order; the skew keeps that stream from waiting on a starved kernel).  It is a property of
+        # the enqueue ORDER (it also runs without streams, which is how the CPU tests cover it).  Streams are kept FEW: the HIP
+        # runtime multiplexes more than 4 streams onto 4 hardware queues (GPU_MAX_HW_QUEUES), where a kernel waiting for an
+        # event blocks the streams behind it -- with one statistics stream per buffer in flight (14 streams at 2 logical shards)
+        # the step took +12 %, and raising GPU_MAX_HW_QUEUES is no way out: oversubscribed hardware queues are time-sliced (one
+        # configuration dropped to 300 ms per step; profiles/r03_tail_ab_queues.txt).  So batches share `n_stats_streams`
+        # statistics streams (per shard) by buffer index modulo, whatever the number of buffers: 2 by default, 1 under a
+        # process group (2 path streams + 1 statistics stream + the process group's own stream = one per hardware queue).
+        # Which streams end up sharing a hardware queue is the runtime's choice, so A/B figures of stream layouts are only
+        # meaningful between fresh processes (bench.py --logical-shards / --skew), not between engines of one process.
+        self.skew = (self.group is not None and self.pipeline) if skew is None else bool(skew)
+        if n_stats_streams is None:
+            n_stats_streams = 1 if self.group is not None else 2
         self.depth = self.N_STAGES if self.skew else 0
         if n_buffers:
             self.n_buf = int(n_buffers) if (self.pipeline or self.skew) else 1
@@ -186,8 +198,22 @@ class PathEngine:
             # alternating path streams: the next batch's path kernel fills the CUs that the previous one's last
             # (partial) round of waves leaves idle; one statistics stream per buffer and shard
             n_ps = max(1, min(int(os.environ.get("MCP_ENGINE_PATH_STREAMS", "2")), self.n_buf * self.S))
-            self.s_paths = [torch.cuda.Stream(self.device) for _ in range(n_ps)]
-            self.s_stats = [[torch.cuda.Stream(self.device, priority=-1) for _ in range(self.S)] for _ in range(self.n_buf)]
+            self.cu_reserve = int(cu_reserve)
+            self._raw_streams = []
+            if self.cu_reserve > 0:
+                # path kernels leave `cu_reserve` compute units to the statistics / exchange kernels of the batches before
+                # (include/mcport.h: mcp_stream_create); torch only wraps the handle
+                self.s_paths = []
+                for _ in range(n_ps):
+                    h = ctypes.c_void_p()
+                    _ffi.check(_ffi.lib().mcp_stream_create(self.device.index or 0, self.cu_reserve, ctypes.byref(h)))
+                    self._raw_streams.append(h)
+                    self.s_paths.append(torch.cuda.ExternalStream(h.value, device=self.device))
+            else:
+                self.s_paths = [torch.cuda.Stream(self.device) for _ in range(n_ps)]
+            ns = max(1, min(int(n_stats_streams), self.n_buf))
+            pool = [[torch.cuda.Stream(self.device, priority=-1) for _ in range(self.S)] for _ in range(ns)]
+            self.s_stats = [pool[i % ns] for i in range(self.n_buf)]          # buffer i -> statistics stream i % ns (per shard)
             self.ev_paths = [[torch.cuda.Event() for _ in range(self.S)] for _ in range(self.n_buf)]
             self.ev_stats = [[torch.cuda.Event() for _ in range(self.S)] for _ in range(self.n_buf)]
             self.ev_x = [[torch.cuda.Event() for _ in range(self.S)] for _ in range(self.n_buf)]      # exchange hand-shakes
@@ -198,7 +224,7 @@ class PathEngine:
             # buffers were filled on the current stream: order every pipeline stream after it
             for sp in self.s_paths:
                 sp.wait_stream(cur)
-            for row in self.s_stats:
+            for row in pool:
                 for ss in row:
                     ss.wait_stream(cur)
 
@@ -360,12 +386,20 @@ class PathEngine:
         if with_stats and self.fused:
             b["hist"].zero_()
 
+    def close(self):
+        """Destroy the streams this engine created through the C ABI (CU-masked path streams)."""
+        if getattr(self, "_raw_streams", None):
+            self.synchronize()
+            for h in self._raw_streams:
+                _ffi.lib().mcp_stream_destroy(h)
+            self._raw_streams = []
+
     def synchronize(self):
         self.flush()
         if self.pipeline:
             for sp in self.s_paths:
                 sp.synchronize()
-            for row in self.s_stats:
+            for row in self.s_stats[:max(1, min(len(self.s_stats), 8))]:
                 for ss in row:
                     ss.synchronize()
         elif self.device.type == "cuda":

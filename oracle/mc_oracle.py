@@ -18,6 +18,8 @@ _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("MCO_LIB_PATH"):            # a sanitizer build of the oracle (tools/asan.sh)
+        return os.environ["MCO_LIB_PATH"]
     so = os.path.join(_HERE, "libmcoracle.so")
     src = os.path.join(_HERE, "mc_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
