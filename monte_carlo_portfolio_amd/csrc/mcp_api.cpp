@@ -53,6 +53,39 @@ int env_sweep_mt() {
 // does a launch for K portfolios go to the MFMA sweep kernels?  (decides the MomentPartial slot count)
 bool uses_sweep(int K) { return K >= SWEEP_MIN_K && env_sweep_mt() >= 0; }
 
+// How a sweep of K portfolios is cut into launches.  Two kernel families, both bit-identical to the oracle:
+//   shared-draw (mc_sweep_shared_kernel): the four waves of a workgroup share one draw and own 128 MT portfolios;
+//                MT = 4 | 2 for N <= 16 (512 | 256 portfolios), MT = 2 | 1 for 16 < N <= 64 (256 | 128)
+//   per-wave    (mc_sweep_kernel, N <= 16): every wave draws for itself and owns 32 MT portfolios, MT = 1 | 2 | 4
+// Whole big shared workgroups first; the remainder r goes to the smallest tiling that covers it:
+//   N <= 16:  r <= 128 per-wave (32 / 64 / 128)   r <= 256 shared MT 2   r <= 384 shared MT 2 + per-wave   else shared MT 4
+//   N  > 16:  r <= 128 shared MT 1                 else shared MT 2
+// (K = 1,250 per GPU when configs[4] is sharded over 8: 2 x 512 + 226 -> one 256-portfolio workgroup row instead of a third 512.)
+struct SweepSeg { bool shared; int mt, k_begin, k_count; };
+int sweep_plan(int K, int nb, SweepSeg* out) {
+  int n = 0;
+  const int env_mt = env_sweep_mt();
+  if (nb <= 4 && env_mt > 0) {                       // forced: per-wave kernel with that many tiles for everything
+    out[n++] = {false, env_mt, 0, K};
+    return n;
+  }
+  const int big = nb <= 4 ? 4 : 2, W = 128 * big;
+  const int full = (K / W) * W;
+  if (full) out[n++] = {true, big, 0, full};
+  const int r = K - full;
+  if (r == 0) return n;
+  if (nb <= 4) {
+    const auto per_wave = [](int k) { return k > 64 ? 4 : (k > 32 ? 2 : 1); };
+    if (r <= 128) out[n++] = {false, per_wave(r), full, r};
+    else if (r <= 256) out[n++] = {true, 2, full, r};
+    else if (r <= 384) { out[n++] = {true, 2, full, 256}; out[n++] = {false, per_wave(r - 256), full + 256, r - 256}; }
+    else out[n++] = {true, 4, full, r};
+  } else {
+    out[n++] = {true, r <= 128 ? 1 : 2, full, r};
+  }
+  return n;
+}
+
 inline int n4_of(int n) { return 4 * ((n + 3) / 4); }
 // W rows are zero-padded to whole MFMA workgroups for a sweep, to whole KT_WIDE passes otherwise
 inline int kpad_of(int k) { return k >= SWEEP_MIN_K ? K_PAD * ((k + K_PAD - 1) / K_PAD) : KT_WIDE * ((k + KT_WIDE - 1) / KT_WIDE); }
@@ -348,30 +381,15 @@ int mcp_launch_paths(const mcp_params* prm, const float* d_packed, const double*
   a.k_count = K;
   a.fold_offset = (uint32_t)(n4_of(prm->n_assets) + n4_of(prm->n_assets) * (n4_of(prm->n_assets) / 2 + 1) + kpad_of(K) * n4_of(prm->n_assets));
   if (sweep) {
-    const int env_mt = env_sweep_mt();
     const bool native = (prm->flags & MCP_FLAG_NATIVE_MATH) != 0;
-    static const int env_shared = [] { const char* e = getenv("MCP_SWEEP_SHARED"); return e ? atoi(e) : 1; }();
-    a.k_begin = 0;
-    // N <= 16: per-wave draw below 384 portfolios, shared draw (512-portfolio workgroups) from there on;
-    // N > 16: always the shared-draw kernel (256-portfolio workgroups)
-    const bool shared = nb > 4 || (K >= 384 && env_shared && !env_mt);
-    // A remainder of at most 256 portfolios behind whole 512-portfolio workgroups (K = 1,250 per GPU when configs[4] is
-    // sharded over 8) runs on the per-wave kernel instead of padding a fourth workgroup: 32-portfolio granularity for
-    // the tail, same arithmetic (all variants are bit-identical to the oracle).
-    const int rem = K % K_PAD;
-    hipError_t e;
-    if (shared && nb <= 4 && K > K_PAD && rem > 0 && rem <= 256) {
-      a.k_count = K - rem;
-      e = mcp::launch_sweep_shared(nb, native, a, (hipStream_t)stream);
-      if (e == hipSuccess) {
-        a.k_begin = K - rem;
-        a.k_count = rem;
-        e = mcp::launch_sweep_paths(nb, rem > 64 ? 4 : (rem > 32 ? 2 : 1), native, a, (hipStream_t)stream);
-      }
-    } else if (shared) {
-      e = mcp::launch_sweep_shared(nb, native, a, (hipStream_t)stream);
-    } else {
-      e = mcp::launch_sweep_paths(nb, env_mt ? env_mt : (K > 64 ? 4 : (K > 32 ? 2 : 1)), native, a, (hipStream_t)stream);
+    SweepSeg segs[4];
+    const int n_seg = sweep_plan(K, nb, segs);
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n_seg && e == hipSuccess; i++) {
+      a.k_begin = segs[i].k_begin;
+      a.k_count = segs[i].k_count;
+      e = segs[i].shared ? mcp::launch_sweep_shared(nb, segs[i].mt, native, a, (hipStream_t)stream)
+                         : mcp::launch_sweep_paths(nb, segs[i].mt, native, a, (hipStream_t)stream);
     }
     if (e != hipSuccess) return fail(MCP_E_HIP, "mc_sweep_kernel launch: %s", hipGetErrorString(e));
     if (d_hist) {                              // digit 0 of the select: one lean read of the terminal values just written

@@ -67,11 +67,11 @@ MCP_DECL_NB(9) MCP_DECL_NB(10) MCP_DECL_NB(11) MCP_DECL_NB(12) MCP_DECL_NB(13) M
 #undef MCP_DECL_NB
 
 // mcp_sweep_paths.hip: MFMA K-portfolio kernels; mt = 32-portfolio tiles per wave (1, 2 or 4)
-hipError_t launch_sweep_shared(int nb, bool native, const PathArgs& args, hipStream_t stream);
-hipError_t launch_sweep_shared_p0(int nb, bool native, const PathArgs& args, hipStream_t stream);
-hipError_t launch_sweep_shared_p1(int nb, bool native, const PathArgs& args, hipStream_t stream);
-hipError_t launch_sweep_shared_p2(int nb, bool native, const PathArgs& args, hipStream_t stream);
-hipError_t launch_sweep_shared_p3(int nb, bool native, const PathArgs& args, hipStream_t stream);
+hipError_t launch_sweep_shared(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream);   // mt: 4|2 (N <= 16), 2|1 (N > 16)
+hipError_t launch_sweep_shared_p0(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream);
+hipError_t launch_sweep_shared_p1(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream);
+hipError_t launch_sweep_shared_p2(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream);
+hipError_t launch_sweep_shared_p3(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream);
 hipError_t launch_sweep_paths(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream);
 hipError_t launch_normals(const uint32_t* x, uint64_t n, const float4* table, float* z, hipStream_t s);
 

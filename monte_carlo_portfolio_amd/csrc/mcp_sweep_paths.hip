@@ -227,9 +227,15 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_kernel(const PathArgs 
 // [32nt + (l&31)], conflict-free), so no permlane is needed.  Two barriers per step suffice without double buffering:
 // z(t+1) is written after barrier 2 of step t (all reads of z(t) precede it), r(t+1) after barrier 1 of step t+1
 // (every wave loads its B operands of step t before reaching it).  Same arithmetic, same order: bit-identical to
-// mc_sweep_kernel and to the oracle.  MT = 4 (512 portfolios per workgroup) for N <= 16, MT = 2 (256) up to N = 64.
+// mc_sweep_kernel and to the oracle.  MT = 4 or 2 (512 / 256 portfolios per workgroup) for N <= 16, MT = 2 or 1 (256 / 128) up to
+// N = 64; the smaller workgroup takes the remainder behind whole big ones (mcp_api.cpp: sweep_plan).
+#ifndef MCP_SHARED_WAVES_SMALL
+#define MCP_SHARED_WAVES_SMALL 4     // __launch_bounds__ minimum waves per SIMD of the shared kernel with MT <= 2, N <= 16: 128 VGPRs (56 B of
+                                     // spills outside the step loop) at 4 waves measured 112.0 against 108.2 TFLOP/s at 3 waves / 164 VGPRs
+                                     // (K = 256 x 262,144 paths, profiles/r03_lab_sweep256.txt)
+#endif
 template <int NB, int MT, bool NATIVE, bool LOGC>
-__global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const PathArgs a) {
+__global__ void __launch_bounds__(PATH_BLOCK, (MT <= 2 && NB <= 4) ? MCP_SHARED_WAVES_SMALL : 2) mc_sweep_shared_kernel(const PathArgs a) {
   constexpr int N4 = 4 * NB, KS = N4 / 2;
   typedef const __attribute__((address_space(4))) float* cfloat_p;
   cfloat_p mu = (cfloat_p)a.packed;
@@ -342,20 +348,27 @@ __global__ void __launch_bounds__(PATH_BLOCK, 2) mc_sweep_shared_kernel(const Pa
   if (a.partials) sweep_moments<MT, LOGC>(a, V, k_base, path0);
 }
 
-template <int NB>
-static hipError_t go_shared(bool native, const PathArgs& args, hipStream_t stream) {
-  constexpr int MT = NB <= 4 ? 4 : 2;
+// Workgroups of 128 MT portfolios: MT = 4 or 2 for N <= 16 (512 / 256), MT = 2 or 1 for 16 < N <= 64 (256 / 128).
+template <int NB, int MT>
+static hipError_t go_shared_mt(bool native, const PathArgs& args, hipStream_t stream) {
   const dim3 grid((unsigned)((args.n_paths + 63) / 64), (unsigned)((args.k_count + 128 * MT - 1) / (128 * MT)));
   const bool lg = args.compounding == MCP_COMPOUND_LOG;
   if (native) { if (lg) mc_sweep_shared_kernel<NB, MT, true, true><<<grid, PATH_BLOCK, 0, stream>>>(args); else mc_sweep_shared_kernel<NB, MT, true, false><<<grid, PATH_BLOCK, 0, stream>>>(args); }
   else { if (lg) mc_sweep_shared_kernel<NB, MT, false, true><<<grid, PATH_BLOCK, 0, stream>>>(args); else mc_sweep_shared_kernel<NB, MT, false, false><<<grid, PATH_BLOCK, 0, stream>>>(args); }
   return hipGetLastError();
 }
+template <int NB>
+static hipError_t go_shared(int mt, bool native, const PathArgs& args, hipStream_t stream) {
+  constexpr int BIG = NB <= 4 ? 4 : 2;
+  if (mt == BIG) return go_shared_mt<NB, BIG>(native, args, stream);
+  if (mt == BIG / 2) return go_shared_mt<NB, BIG / 2>(native, args, stream);
+  return hipErrorInvalidValue;
+}
 
-// K rows of W must be zero-padded to a multiple of 512 (mcp_pack_params pads to K_PAD).
-hipError_t MCP_CAT(launch_sweep_shared_p, MCP_SWEEP_PART)(int nb, bool native, const PathArgs& args, hipStream_t stream) {
+// W rows must be zero-padded to a multiple of 512 (mcp_pack_params pads to K_PAD).
+hipError_t MCP_CAT(launch_sweep_shared_p, MCP_SWEEP_PART)(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream) {
   switch (nb) {
-#define MCP_CASE(n) case n: return go_shared<n>(native, args, stream);
+#define MCP_CASE(n) case n: return go_shared<n>(mt, native, args, stream);
 #if MCP_SWEEP_PART == 0
     MCP_CASE(1) MCP_CASE(2) MCP_CASE(3) MCP_CASE(4)
 #elif MCP_SWEEP_PART == 1
@@ -371,13 +384,13 @@ hipError_t MCP_CAT(launch_sweep_shared_p, MCP_SWEEP_PART)(int nb, bool native, c
 }
 
 #if MCP_SWEEP_PART == 0
-hipError_t launch_sweep_shared(int nb, bool native, const PathArgs& args, hipStream_t stream) {
+hipError_t launch_sweep_shared(int nb, int mt, bool native, const PathArgs& args, hipStream_t stream) {
   if (nb < 1 || nb > 16) return hipErrorInvalidValue;
   switch ((nb - 1) / 4) {
-    case 0: return launch_sweep_shared_p0(nb, native, args, stream);
-    case 1: return launch_sweep_shared_p1(nb, native, args, stream);
-    case 2: return launch_sweep_shared_p2(nb, native, args, stream);
-    default: return launch_sweep_shared_p3(nb, native, args, stream);
+    case 0: return launch_sweep_shared_p0(nb, mt, native, args, stream);
+    case 1: return launch_sweep_shared_p1(nb, mt, native, args, stream);
+    case 2: return launch_sweep_shared_p2(nb, mt, native, args, stream);
+    default: return launch_sweep_shared_p3(nb, mt, native, args, stream);
   }
 }
 

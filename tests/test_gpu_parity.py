@@ -231,6 +231,42 @@ def test_mfma_sweep_kernel_bit_exact(gpu_ctx, N, K, P, T, comp):
     assert int(np.argmax(sharpe)) == int(np.argmax(want))
 
 
+# Every branch of the sweep dispatch (csrc/mcp_api.cpp: sweep_plan), each against the oracle bit for bit: whole shared-draw
+# workgroups (512 / 256 portfolios at N <= 16, 256 / 128 beyond), then the remainder on the smallest tiling that covers it.
+SWEEP_CASES = [
+    # N <= 16: per-wave kernel with 1 / 2 / 4 tiles (K <= 128), shared MT 2 (129..256), shared MT 2 + per-wave (257..384), shared MT 4
+    (16, 17), (16, 33), (16, 65), (16, 128), (16, 129), (16, 256), (16, 257), (16, 300), (16, 384), (16, 385), (16, 512),
+    # ... behind whole 512-portfolio workgroups: remainders 1, 8, 17, 128, 226 (configs[4] over 8 GPUs: K = 1,250), 256, 288, 452
+    (16, 513), (16, 520), (16, 529), (16, 640), (16, 1250), (16, 768), (16, 800), (16, 964),
+    (5, 700), (12, 1100),
+    # 16 < N <= 64: shared MT 1 (128) / MT 2 (256), and the remainder behind whole 256-portfolio workgroups
+    (20, 17), (20, 128), (20, 129), (20, 256), (20, 300), (33, 513), (64, 130),
+]
+
+
+@pytest.mark.parametrize("N,K", SWEEP_CASES)
+@pytest.mark.parametrize("mode", ["simple", "log", "native"])
+def test_sweep_dispatch_every_branch(gpu_ctx, N, K, mode):
+    if mode != "simple" and (K, N) not in ((300, 16), (520, 16), (1250, 16), (129, 20), (300, 20), (128, 16)):
+        pytest.skip("the other compounding / math modes on a subset of the branches")
+    T, P = 6, 333                                     # ragged: 333 paths = five 64-path wave tiles + 13
+    comp = "log" if mode == "log" else "simple"
+    if mode == "native":                              # hardware Box-Muller: other values, so the check is internal consistency
+        mu, cov = synthetic.synthetic_market(N)
+        W = synthetic.dirichlet_weights(N, K)
+        a = simulate_paths(mu, cov, W, n_steps=T, n_paths=P, seed=SEED, store=True, native_math=True, as_array=True)
+        b = [simulate_paths(mu, cov, W[k], n_steps=T, n_paths=P, seed=SEED, store=True, native_math=True) for k in (0, K // 2, K - 1)]
+        for i, k in enumerate((0, K // 2, K - 1)):    # the K-portfolio kernels against the one-portfolio kernel
+            np.testing.assert_allclose(a[1][k], b[i]["terminal"], rtol=2e-6)
+            assert a[0][k]["n_tail"] == b[i]["n_tail"]
+        return
+    got, ref = run_both(N, T, P, K=K, compounding=comp, rf=0.0005)
+    for k in range(K):
+        assert np.array_equal(got[k]["terminal"].view(np.uint32), ref[k].view(np.uint32)), k
+    for k in (0, 1, K // 3, K // 2, K - 2, K - 1):
+        assert_stats(got[k], ref[k], 1.0, comp, 0.95, 0.0005, exact_quantile=(comp == "simple"))
+
+
 def test_config0_csv_to_simulated_stats(gpu_ctx):
     """BASELINE configs[0] end to end: the three daily CSVs -> returns -> (mu, Sigma) -> 10k paths x 252 steps,
     against the oracle on the same inputs (the reference itself cannot load these files)."""

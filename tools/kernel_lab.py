@@ -21,19 +21,19 @@ def build(specs):
         print(name, "ok" if r.returncode == 0 else "FAILED\n" + r.stdout[-2000:] + r.stderr[-2000:])
 
 
-def run(names, paths, rounds, assets, steps, native, stats=True):
+def run(names, paths, rounds, assets, steps, native, stats=True, K=1):
     import numpy as np, torch
     from monte_carlo_portfolio_amd import _ffi, synthetic
     from monte_carlo_portfolio_amd.simulate import prepare_inputs
     base = _ffi.lib()     # binds signatures; also decides the HIP runtime
     mu, cov = synthetic.synthetic_market(assets)
-    mu32, L, W32 = prepare_inputs(mu, cov, synthetic.equal_weights(assets))
-    prm = _ffi.make_params(assets, steps, 1, native_math=native)
+    mu32, L, W32 = prepare_inputs(mu, cov, synthetic.equal_weights(assets) if K == 1 else synthetic.dirichlet_weights(assets, K))
+    prm = _ffi.make_params(assets, steps, K, native_math=native)
     packed = torch.from_numpy(_ffi.pack_params(mu32, L, W32)).cuda()
-    term = torch.empty((1, paths), dtype=torch.float32, device="cuda")
+    term = torch.empty((K, paths), dtype=torch.float32, device="cuda")
     pivot = torch.from_numpy(_ffi.pivots(prm, mu32, L, W32)).cuda()
-    partials = torch.zeros(base.mcp_ws_bytes(_ffi.WS_PARTIALS, 1, paths) // 8, dtype=torch.int64, device="cuda")
-    hist = torch.zeros(base.mcp_ws_bytes(_ffi.WS_HIST, 1, paths) // 8, dtype=torch.int64, device="cuda")
+    partials = torch.zeros(base.mcp_ws_bytes(_ffi.WS_PARTIALS, K, paths) // 8, dtype=torch.int64, device="cuda")
+    hist = torch.zeros(base.mcp_ws_bytes(_ffi.WS_HIST, K, paths) // 8, dtype=torch.int64, device="cuda")
     libs = {}
     for n in names:
         path = _ffi.LIB_PATH if n == "base" else os.path.join(LAB, f"libmcport_{n}.so")
@@ -66,7 +66,8 @@ def run(names, paths, rounds, assets, steps, native, stats=True):
             times[n].append(e0.elapsed_time(e1) / 2)
     for n in names:
         ts = times[n]
-        print(f"{n:>14}: median {statistics.median(ts):.3f} ms  min {min(ts):.3f} ms  -> {paths / statistics.median(ts) * 1e3:.4e} paths/s")
+        tf = f"  W.r product {2.0 * K * assets * paths * steps / statistics.median(ts) / 1e9:.1f} TFLOP/s" if K > 1 else ""
+        print(f"{n:>14}: median {statistics.median(ts):.3f} ms  min {min(ts):.3f} ms  -> {paths / statistics.median(ts) * 1e3:.4e} paths/s{tf}")
 
 
 if __name__ == "__main__":
@@ -80,5 +81,6 @@ if __name__ == "__main__":
         ap.add_argument("--assets", type=int, default=16); ap.add_argument("--steps", type=int, default=252)
         ap.add_argument("--native", action="store_true")
         ap.add_argument("--no-stats", action="store_true", help="terminal values only (no fused statistics epilogue)")
+        ap.add_argument("--portfolios", type=int, default=1, help="K > 16: the MFMA sweep kernels (the launch then includes the lean digit-0 pass)")
         a = ap.parse_args()
-        run(a.names, a.paths, a.rounds, a.assets, a.steps, a.native, not a.no_stats)
+        run(a.names, a.paths, a.rounds, a.assets, a.steps, a.native, not a.no_stats, a.portfolios)
