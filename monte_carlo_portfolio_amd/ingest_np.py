@@ -14,6 +14,14 @@ reference-generated goldens G1-G3 and by `ingest.py`, the pandas twin, on every 
 `compat=True` reproduces quirk Q1 (a thousands separator makes the whole column text, which then fails to convert and is
 dropped); the default strips separators.  Dates: the format is inferred from the first row as pandas does for these
 files (month first unless the first field exceeds 12); unparsable rows are dropped (`errors='coerce'`).
+
+Scope of the date parser.  `pd.to_datetime` guesses among many more layouts than a price export ever uses; this module
+accepts the ones in `_DATE_FORMATS` (the layouts of the 16 shipped files and of the common exchange / Yahoo / investing.com
+exports, ISO timestamps included) and says so when it meets another one: such a file is REJECTED with a message naming the
+supported layouts (the pandas twin `ingest.read_csv_file` accepts whatever pandas accepts).  Pinned against pandas on every
+listed layout (`tests/test_ingest_np.py::test_date_layouts_agree_with_pandas`).  Two more documented differences: a date
+that occurs twice in one file keeps its first price (pandas' inner join would pair every duplicate), and a 0/0 return is
+0.0 as `fillna(0)` makes it.
 """
 from __future__ import annotations
 
@@ -27,7 +35,12 @@ import numpy as np
 
 PRICE_NAMES = ("price", "close", "adj close", "open")
 ANNUAL_FACTOR = {"M": 12, "Q": 4, "W": 52, "D": 252}
-_DATE_FORMATS = ("%m/%d/%Y", "%d/%m/%Y", "%Y-%m-%d", "%Y/%m/%d", "%b %d, %Y", "%d-%m-%Y", "%Y-%m-%d %H:%M:%S", "%m/%d/%y")
+_DATE_FORMATS = ("%m/%d/%Y", "%d/%m/%Y", "%Y-%m-%d", "%Y/%m/%d", "%b %d, %Y", "%d-%m-%Y", "%Y-%m-%d %H:%M:%S", "%m/%d/%y",
+                 "%Y-%m-%dT%H:%M:%S", "%Y-%m-%dT%H:%M:%SZ", "%Y-%m-%dT%H:%M:%S.%f", "%Y-%m-%d %H:%M:%S.%f", "%Y-%m-%d %H:%M",
+                 "%d.%m.%Y", "%Y%m%d", "%b %d %Y", "%d %b %Y", "%B %d, %Y", "%d-%b-%Y", "%d-%b-%y")
+SUPPORTED_DATE_LAYOUTS = ("01/31/2020 or 31/01/2020 (month first unless the first field exceeds 12), 2020-01-31, 2020/01/31, 31-01-2020, "
+                          "31.01.2020, 20200131, Jan 31, 2020, Jan 31 2020, 31 Jan 2020, January 31, 2020, 31-Jan-2020, 31-Jan-20, 01/31/20, "
+                          "2020-01-31 16:00[:00[.ffffff]], 2020-01-31T16:00:00[.ffffff][Z]")
 
 
 def _default_report(msg: str) -> None:
@@ -187,6 +200,8 @@ def read_csv_file(file, compat: bool = False, report=None):
         dates = _parse_dates(ds)
         keep = (dates != np.iinfo(np.int64).min) & ~np.isnan(prices)
         if not keep.any():
+            if (dates == np.iinfo(np.int64).min).all() and not np.isnan(prices).all():
+                raise ValueError(f"no date could be parsed (first value {ds[0]!r}); supported layouts: {SUPPORTED_DATE_LAYOUTS}")
             raise ValueError("no valid rows left after type conversion")
         return dates[keep], prices[keep]
     except Exception as e:                                   # the reference catches everything here
@@ -248,10 +263,13 @@ def align_prices(named_series, resample_rule: str = "M"):
 
 
 def returns_matrix(resampled: np.ndarray) -> np.ndarray:
-    """app.py:666-667: `pct_change().fillna(0)` per column, first row 0.0 kept."""
+    """app.py:666-667: `pct_change().fillna(0)` per column, first row 0.0 kept.  0/0 (two consecutive zero prices) is NaN in
+    `pct_change` and 0.0 after `fillna(0)`; x/0 stays +-inf there and here."""
     R = np.zeros_like(resampled)
     if resampled.shape[0] > 1:
-        R[1:] = resampled[1:] / resampled[:-1] - 1.0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            R[1:] = resampled[1:] / resampled[:-1] - 1.0
+        R[np.isnan(R)] = 0.0
     return R
 
 

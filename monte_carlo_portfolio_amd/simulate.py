@@ -42,6 +42,15 @@ class Context:
         portfolios (include/mcport.h, mcp_ctx_set_terminal_budget)."""
         _ffi.check(_ffi.lib().mcp_ctx_set_terminal_budget(self._h, int(nbytes)))
 
+    def exchange(self):
+        """(mode, note): how the shards of this context exchange histograms and records -- 'unset' before the first
+        path-sharded call, then 'none' (one shard), 'rccl', 'kernel' (logical shards of one device) or 'p2p' (distinct devices
+        without RCCL: the kernel over peer access; `note` then says why RCCL was not used)."""
+        lib = _ffi.lib()
+        names = {_ffi.EXCHANGE_UNSET: "unset", _ffi.EXCHANGE_NONE: "none", _ffi.EXCHANGE_RCCL: "rccl", _ffi.EXCHANGE_KERNEL: "kernel",
+                 _ffi.EXCHANGE_P2P: "p2p"}
+        return names[lib.mcp_ctx_exchange_mode(self._h)], lib.mcp_ctx_exchange_note(self._h).decode("utf-8", "replace")
+
     def close(self):
         if self._h:
             _ffi.lib().mcp_ctx_destroy(self._h)

@@ -194,8 +194,10 @@ def test_same_device_shards_equal_one_device(gpu_ctx, devices, P, K):
     ctx = Context(devices)
     try:
         assert _ffi.lib().mcp_ctx_device_count(ctx._h) == len(devices)
+        assert ctx.exchange() == ("unset", "")               # nothing is set up before the first path-sharded call
         many = simulate_paths(mu, cov, W, n_steps=25, n_paths=P, seed=11, store=True, rf=0.002, as_array=True, context=ctx,
                               devices=devices, shard="paths")
+        assert ctx.exchange() == ("kernel", "")              # logical shards of one device: the sum kernel, and it says so
     finally:
         ctx.close()
     assert np.array_equal(one[1].view(np.uint32), many[1].view(np.uint32))            # terminal values, in path order
@@ -274,6 +276,8 @@ _ffi.preload_rccl()
 mu, cov = synthetic.synthetic_market(16); w = synthetic.equal_weights(16)
 ctx = Context(0)
 r = simulate_paths(mu, cov, w, n_steps=30, n_paths=50_000, seed=5, context=ctx)
+import os
+assert ctx.exchange()[0] == ("rccl" if os.environ["MCP_FORCE_RCCL"] == "1" else "none"), ctx.exchange()
 print(r["n"], r["n_tail"], r["var"].hex(), r["cvar"].hex(), r["sharpe"].hex())
 """
     outs = []
@@ -285,6 +289,41 @@ print(r["n"], r["n_tail"], r["var"].hex(), r["cvar"].hex(), r["sharpe"].hex())
     assert outs[0][:3] == outs[1][:3] and outs[0][0] == "50000" and outs[0][1] == "2500"
     for a, b in zip(outs[0][3:], outs[1][3:]):
         assert float.fromhex(a) == pytest.approx(float.fromhex(b), rel=1e-14)
+
+
+def test_portfolio_sharded_context_needs_no_exchange(gpu_ctx):
+    """MCP_FLAG_SHARD_PORTFOLIOS: every shard walks all paths for its slice of the weights -- no communicator, no peer mapping
+    is ever set up (the exchange is created lazily, by the first PATH-sharded call only), and the records equal the
+    one-device ones bit for bit (same kernels, same order)."""
+    mu, cov = synthetic.synthetic_market(16)
+    W = synthetic.dirichlet_weights(16, 1100)
+    one = simulate_paths(mu, cov, W, n_steps=12, n_paths=4096, seed=3, as_array=True)
+    ctx = Context([0, 0, 0])
+    try:
+        many = simulate_paths(mu, cov, W, n_steps=12, n_paths=4096, seed=3, as_array=True, context=ctx, devices=[0, 0, 0], shard="portfolios")
+        assert ctx.exchange() == ("unset", "")
+    finally:
+        ctx.close()
+    for key in ("n", "n_tail", "var", "min", "max"):
+        assert np.array_equal(one[key], many[key]), key
+    for key in ("mean", "std", "sharpe", "cvar"):        # the per-launch partial grids differ with the slice size: association only
+        np.testing.assert_allclose(many[key], one[key], rtol=1e-13)
+
+
+def test_a_failed_call_leaves_the_context_usable(gpu_ctx):
+    """A pass that stops half way (here: an argument the library refuses after the first tile has run) must not leave counts
+    in the read-and-clear histograms: the next call on the same context gives the clean result."""
+    mu, cov = synthetic.synthetic_market(16)
+    w = synthetic.equal_weights(16)
+    ctx = Context(0)
+    try:
+        good = simulate_paths(mu, cov, w, n_steps=20, n_paths=30_000, seed=9, context=ctx)
+        with pytest.raises(_ffi.McpError):
+            simulate_paths(mu, cov, w, n_steps=2**31 - 1, n_paths=1000, seed=9, context=ctx)      # 2^31 steps x 4 blocks: Philox counter overflow
+        again = simulate_paths(mu, cov, w, n_steps=20, n_paths=30_000, seed=9, context=ctx)
+    finally:
+        ctx.close()
+    assert good == again
 
 
 def test_terminal_budget_tiles_the_portfolios(gpu_ctx):

@@ -220,3 +220,43 @@ def test_fuzz_alignment_and_resampling_equal_the_pandas_pipeline():
                 mean, cov = ingest_np.sweep_inputs(R, 12)
                 assert np.array_equal((rets.mean() * 12).values, mean)
                 assert np.array_equal(np.atleast_2d((rets.cov() * 12).values), cov)
+
+
+@pytest.mark.parametrize("layout", ["%m/%d/%Y", "%Y-%m-%d", "%Y/%m/%d", "%b %d, %Y", "%d-%m-%Y", "%Y-%m-%d %H:%M:%S", "%Y-%m-%dT%H:%M:%S",
+                                    "%Y-%m-%dT%H:%M:%SZ", "%d.%m.%Y", "%Y%m%d", "%b %d %Y", "%d %b %Y", "%B %d, %Y", "%d-%b-%Y", "%Y-%m-%d %H:%M"])
+def test_date_layouts_agree_with_pandas(layout):
+    """Every date layout the pandas-free reader documents (ingest_np.SUPPORTED_DATE_LAYOUTS) against the pandas twin, which
+    parses with `pd.to_datetime(errors='coerce')` as the reference does (app.py:124): same rows kept, same days, same prices."""
+    import datetime as dt
+    from monte_carlo_portfolio_amd import ingest
+    rng = np.random.default_rng(len(layout))
+    days = [dt.datetime(2019, 1, 13, 16, 0, 0) + dt.timedelta(days=int(d)) for d in np.cumsum(rng.integers(1, 9, 40))]
+    prices = np.round(100 * np.exp(np.cumsum(rng.normal(0, 0.02, 40))), 2)
+    quote = "," in dt.datetime(2020, 1, 1).strftime(layout)
+    lines = ["Date,Price"] + [(f'"{d.strftime(layout)}"' if quote else d.strftime(layout)) + f",{p}" for d, p in zip(days, prices)]
+    lines.insert(7, "not a date,12.5")                                  # coerced to NaT and dropped by both
+    text = "\n".join(lines) + "\n"
+
+    def f():
+        b = io.BytesIO(text.encode()); b.name = "x.csv"
+        return b
+    want = ingest.read_csv_file(f(), report=lambda m: None)
+    got = ingest_np.read_csv_file(f(), report=lambda m: None)
+    assert want is not None and got is not None
+    want_days = (want["Date"].values.astype("datetime64[D]").astype(np.int64))
+    assert np.array_equal(got[0], want_days) and np.array_equal(got[1], want["Price"].values)
+
+
+def test_unsupported_date_layout_is_reported_not_guessed():
+    msgs = []
+    b = io.BytesIO(b"Date,Price\n2020-W05-1,10\n2020-W06-1,11\n"); b.name = "w.csv"
+    assert ingest_np.read_csv_file(b, report=msgs.append) is None
+    assert "supported layouts" in msgs[0] and "2020-01-31" in msgs[0]
+
+
+def test_zero_over_zero_return_is_zero_as_fillna_makes_it():
+    import pandas as pd
+    P = np.array([[1.0, 0.0], [2.0, 0.0], [1.0, 3.0]])
+    R = ingest_np.returns_matrix(P)
+    want = pd.DataFrame(P).pct_change().fillna(0).values
+    assert np.array_equal(R, want) and R[1, 1] == 0.0 and np.isinf(R[2, 1])
