@@ -39,6 +39,13 @@ namespace mcp {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifdef MCP_DIAG_CLOCK
+// Diagnostic build only (tools/clock_probe.py; MI355X_MICROARCH.md, DVFS give-back item 6): every workgroup of mc_paths_kernel
+// stamps s_memtime (shader cycles) and s_memrealtime (100 MHz) around its step loops into a buffer of its own that nothing
+// else reads; in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz.  No stamp executes in the product build.
+extern __device__ unsigned long long mcp_diag_stamps[2 * 8192];
+#endif
+
 struct PathArgs {
   const float* __restrict__ packed;   // [mu N4][L row pairs N4(N4/2+1)][W Kpad*N4]  (mcp_pack_params)
   float* __restrict__ terminal;       // [K][stride]
@@ -167,6 +174,9 @@ mc_paths_kernel(const PathArgs a) {
 
   const uint64_t tile = (uint64_t)PATH_BLOCK * PPT;
   const uint64_t n_tiles = (a.n_paths + tile - 1) / tile;
+#ifdef MCP_DIAG_CLOCK
+  const unsigned long long diag_t0 = __builtin_amdgcn_s_memtime(), diag_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (uint64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
     uint64_t p[PPT];
     bool live[PPT];
@@ -313,6 +323,12 @@ mc_paths_kernel(const PathArgs a) {
     }
   }
 
+#ifdef MCP_DIAG_CLOCK
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    mcp_diag_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - diag_t0;
+    mcp_diag_stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - diag_r0;
+  }
+#endif
   asm volatile("" : "+s"(kargs));
   if (kargs->partials != nullptr) {
     __syncthreads();

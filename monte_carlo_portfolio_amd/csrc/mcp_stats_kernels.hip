@@ -31,6 +31,14 @@
 #include "mcp_paths.h"
 #include "mcp_stats_kernels.h"
 
+#ifdef MCP_DIAG_CLOCK
+namespace mcp { __device__ unsigned long long mcp_diag_stamps[2 * 8192]; }
+// diagnostic build only: copies the stamps of the last mc_paths_kernel launch to the host (2 x n words)
+extern "C" int mcp_diag_read(unsigned long long* out, int n_blocks) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mcp::mcp_diag_stamps), (size_t)n_blocks * 2 * sizeof(unsigned long long));
+}
+#endif
+
 namespace mcp {
 
 constexpr int SB = 256;                               // threads per block of every kernel here

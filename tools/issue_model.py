@@ -14,8 +14,9 @@ cycles per wave-instruction per SIMD at 8 waves/SIMD) and writes the table bench
   v_mad_u64_u32                                                              4.7
   v_log/exp/sqrt/rcp/rsq/sin/cos_f32                                         8.2
 
-The clock is the one measured under this kernel's load (GRBM_GUI_ACTIVE / 8 / kernel time of the PMC pass), not the nominal
-2.4 GHz.  It is a builder-authored model, NOT a hardware peak: the primary roofline.frac is against the 157.3 TFLOP/s fp32
+The clock is the one measured INSIDE the un-profiled kernel under its own load (tools/clock_probe.py: s_memtime /
+s_memrealtime stamps of a diagnostic build, profiles/r03_clock.txt: 2.30 GHz), not the nominal 2.4 GHz and not the clock under
+the profiler (GRBM_GUI_ACTIVE / 8 / kernel time of a --pmc pass: 1.97 GHz, where the same kernel takes 18 % longer).  It is a builder-authored model, NOT a hardware peak: the primary roofline.frac is against the 157.3 TFLOP/s fp32
 vector peak of MI355X_MICROARCH.md.
 """
 import argparse
@@ -74,7 +75,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nb", type=int, default=4)
     ap.add_argument("--clock-hz", type=float, default=None)
-    ap.add_argument("--pmc", default=None, help="pmc summary JSON (tools/pmc_summary.py): takes the clock under load from it")
+    ap.add_argument("--pmc", default=None, help="pmc summary JSON (tools/pmc_summary.py): takes the clock under the profiler from it")
+    ap.add_argument("--clock-source", default=None, help="where --clock-hz comes from (e.g. profiles/r03_clock.txt)")
     ap.add_argument("-o", "--out", default=None)
     a = ap.parse_args()
     with tempfile.TemporaryDirectory() as td:
@@ -99,11 +101,14 @@ def main():
         key = (cls, op.replace("_e32", "").replace("_e64", ""))
         rows.setdefault(key, [0, cyc])[0] += 1
     clock = a.clock_hz
-    src = "command line"
+    src = a.clock_source or "command line"
+    prof_clock = None
     if a.pmc:
         p = json.load(open(a.pmc))
-        clock = p["kernel_cycles"] / (p["kernel_ms_under_pmc"] * 1e-3)
-        src = f"{os.path.relpath(a.pmc, ROOT)}: GRBM_GUI_ACTIVE / 8 / kernel time of the PMC pass"
+        prof_clock = p["kernel_cycles"] / (p["kernel_ms_under_pmc"] * 1e-3)
+        if clock is None:
+            clock = prof_clock
+            src = f"{os.path.relpath(a.pmc, ROOT)}: GRBM_GUI_ACTIVE / 8 / kernel time of the PMC pass (the clock UNDER THE PROFILER)"
     if clock is None:
         clock = 2.4e9
         src = "nominal (no measurement given)"
@@ -115,7 +120,7 @@ def main():
                 "(profiles/r01_valu_rates.txt, 8 waves/SIMD) and at the clock measured under this kernel's load.  Builder-authored model, "
                 "NOT a hardware peak: roofline.frac in the bench line is against the 157.3 TFLOP/s fp32 vector peak." % (a.nb, label),
         "generated_by": "tools/issue_model.py",
-        "clock_hz": clock, "clock_source": src, "simds": 1024,
+        "clock_hz": clock, "clock_source": src, "clock_hz_under_profiler": prof_clock, "simds": 1024,
         "valu_insts_per_wave_step": n, "other_insts_per_wave_step": dict(other),
         "rows": table, "cycles_per_wave_step": total,
         "by_class": {c: sum(r["count"] * r["cycles"] for r in table if r["class"] == c) for c in dict.fromkeys(r["class"] for r in table)},
