@@ -34,5 +34,7 @@ python3 bench.py --steps 40 --warmup 5 $B > $O/bench_1shard.json 2>/dev/null
 python3 bench.py --steps 40 --warmup 5 $B --logical-shards 2 > $O/bench_2shards.json 2>/dev/null
 python3 bench.py --steps 40 --warmup 5 $B --logical-shards 2 --skew 1 --stats-streams 1 > $O/bench_2shards_skew.json 2>/dev/null
 python3 tools/config4_full.py > $O/config4_full.txt 2>&1 || true
+python3 tools/sweep_hist_probe.py 2>&1 | grep -v amdgpu.ids > $O/sweep_hist.txt || true
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/sweep_hist -- python3 $R/tools/sweep_hist_probe.py 4096 16 2500 > /dev/null 2>&1; cp $O/sweep_hist/*/*_kernel_stats.csv $O/sweep_hist_kernel_stats.csv; rm -rf $O/sweep_hist) || true
 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 tail -3 $O/hostcall.txt; tail -2 $O/overlap.txt; cat $O/tail_1shard.txt | head -4; cat $O/tail_2shards.txt | head -4
