@@ -163,6 +163,36 @@ def test_path_engine_single_rank_matches_host_level(gpu_ctx):
             assert st[k][key] == host[k][key], key
 
 
+@pytest.mark.parametrize("kw", [dict(logical_shards=2), dict(logical_shards=3, skew=True), dict(logical_shards=2, skew=True, n_stats_streams=1),
+                                dict(logical_shards=8), dict(cu_reserve=4), dict(skew=True), dict(n_buffers=3, n_stats_streams=3)])
+@pytest.mark.parametrize("K", [1, 20])
+def test_path_engine_layouts_equal_the_plain_engine(gpu_ctx, kw, K):
+    """Every stream / schedule / shard layout of PathEngine on the real kernels: logical shards exchanging through the sum
+    kernel (the N > 1 choreography on one GPU), the skewed enqueue order, one or several statistics streams, CU-masked path
+    streams.  Nine pipelined batches over a cycle of seeds; the last must equal the plain engine's result for its seed:
+    terminal values, counts and order statistics exactly, fp64 sums to 1e-13."""
+    from monte_carlo_portfolio_amd.engine import PathEngine
+    N, T, P = 16, 24, 30_011
+    mu, cov = synthetic.synthetic_market(N)
+    W = synthetic.equal_weights(N) if K == 1 else synthetic.dirichlet_weights(N, K)
+    mu32, L, W32 = prepare_inputs(mu, cov, W)
+    ref = PathEngine(mu32, L, W32, T, P, rf=0.001, pipeline=False)
+    ref.step(SEED)
+    want, want_term = ref.stats(), ref.terminal()
+    eng = PathEngine(mu32, L, W32, T, P, rf=0.001, **kw)
+    for i in range(9):
+        eng.step(SEED + 8 - i)
+    got = eng.stats()
+    assert np.array_equal(eng.terminal().view(np.uint32), want_term.view(np.uint32))
+    for key in ("n", "n_tail", "var", "x_lo", "x_hi", "min", "max"):
+        assert np.array_equal(got[key], want[key]), key
+    for key in ("mean", "std", "sharpe", "cvar"):
+        np.testing.assert_allclose(got[key], want[key], rtol=1e-13)
+    eng.step(SEED)
+    assert np.array_equal(eng.stats()["var"], want["var"])
+    eng.close()
+
+
 ENGINE_WORKER = r"""
 import json, os, sys
 sys.path.insert(0, {root!r})
