@@ -377,13 +377,14 @@ class PathEngine:
         while self.stage_done:
             self._advance(min(self.stage_done))
 
-    def launch_paths_only(self, seed: int, path_base: int = 0, with_stats: bool = True):
+    def launch_paths_only(self, seed: int, path_base: int = 0, with_stats: bool = True, clear_hist: bool = True):
         """The dominant kernel alone (with its fused epilogue), on the CURRENT stream into the most recent buffer
         (roofline timing).  Call synchronize() first if batches enqueued by step() may still be in flight.  The digit-0
-        counts the epilogue leaves in the histogram are cleared again (nothing consumes them here)."""
+        counts the epilogue leaves in the histogram are cleared again (nothing consumes them here); a timing loop passes
+        clear_hist=False and clears once at the end, so that no fill kernel sits between the timed launches."""
         b = self.bufs[self.last][0]
         self._enqueue_paths(b, seed, path_base, with_stats)
-        if with_stats and self.fused:
+        if with_stats and self.fused and clear_hist:
             b["hist"].zero_()
 
     def close(self):

@@ -80,7 +80,10 @@ __global__ void __launch_bounds__(1024) coexec(float* out, unsigned long long* c
   for (int i = 0; i < 16; i++) s += acc32[0][i] + acc32[1][i];
   for (int i = 0; i < 4; i++) s += acc16[i].x + acc16[i].y + acc16[i].z + acc16[i].w;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s + (float)su;
-  if (threadIdx.x == 0) { cyc[2 * blockIdx.x] = t1 - t0; cyc[2 * blockIdx.x + 1] = r1 - r0; }
+  if ((threadIdx.x & 63) == 0) {                       // every wave reports: the SIMD's time is the longest lifetime among its waves
+    const int w = blockIdx.x * 16 + (threadIdx.x >> 6);
+    cyc[2 * w] = t1 - t0; cyc[2 * w + 1] = r1 - r0;
+  }
 }
 
 struct Result { double cycles_per_iter, ghz; };
@@ -92,10 +95,17 @@ Result run(int wps, float* d_out, unsigned long long* d_cyc, int num_cu) {
   CHECK(hipDeviceSynchronize());
   coexec<MF, FILL, NF><<<blocks, 256 * wps>>>(d_out, d_cyc, 1.0001f, 0x9E3779B9u);
   CHECK(hipDeviceSynchronize());
-  std::vector<unsigned long long> h(2 * blocks);
-  CHECK(hipMemcpy(h.data(), d_cyc, 2 * blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> h(2 * 16 * blocks);
+  CHECK(hipMemcpy(h.data(), d_cyc, 2 * 16 * blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   std::vector<double> c(blocks), g(blocks);
-  for (int b = 0; b < blocks; b++) { c[b] = (double)h[2 * b] / ITERS; g[b] = (double)h[2 * b] / (double)h[2 * b + 1] * 0.1; }
+  for (int b = 0; b < blocks; b++) {                    // per workgroup: the longest wave lifetime (all its waves start together)
+    double mx = 0, clk = 0;
+    for (int w = 0; w < 4 * wps; w++) {
+      const double cy = (double)h[2 * (b * 16 + w)], rt = (double)h[2 * (b * 16 + w) + 1];
+      if (cy > mx) { mx = cy; clk = cy / rt * 0.1; }
+    }
+    c[b] = mx / ITERS; g[b] = clk;
+  }
   std::sort(c.begin(), c.end()); std::sort(g.begin(), g.end());
   return {c[blocks / 2], g[blocks / 2]};
 }
@@ -116,11 +126,11 @@ void report(const char* mf_name, const char* fill_name, float* d_out, unsigned l
 int main() {
   hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
   const int num_cu = prop.multiProcessorCount;
-  printf("device %s  CUs=%d  (cycles are wave-lifetime shader cycles per loop iteration of ONE wave; at w waves/SIMD the SIMD "
-         "spends cycles/w per iteration)\n", prop.gcnArchName, num_cu);
+  printf("device %s  CUs=%d  (cycles = shader cycles per loop iteration of the LONGEST-lived wave of a workgroup of 4 w waves, w per "
+         "SIMD: what the SIMD needs for w iterations' worth of work)\n", prop.gcnArchName, num_cu);
   float* d_out; unsigned long long* d_cyc;
   CHECK(hipMalloc(&d_out, (size_t)num_cu * 1024 * sizeof(float)));
-  CHECK(hipMalloc(&d_cyc, (size_t)num_cu * 4 * 2 * sizeof(unsigned long long)));
+  CHECK(hipMalloc(&d_cyc, (size_t)num_cu * 16 * 2 * sizeof(unsigned long long)));
 #define ROWS(MF, NAME)                                                            \
   report<MF, F_FMA, 8>(NAME, "v_fma_f32", d_out, d_cyc, num_cu);                  \
   report<MF, F_PKFMA, 8>(NAME, "v_pk_fma_f32", d_out, d_cyc, num_cu);             \
