@@ -26,7 +26,8 @@
                             // VGPRs; forced into 72 for 7 waves it spills 24 B per lane outside the loop and is 0.5 % slower)
 #endif
 #ifndef MCP_MIN_WAVES_BIG
-#define MCP_MIN_WAVES_BIG 1 // the same for 16 < N <= 64, one portfolio (experiment: 4 forces <= 128 VGPRs)
+#define MCP_MIN_WAVES_BIG 1 // the same for 16 < N <= 64, one portfolio.  4 (<= 128 VGPRs) was measured: the 64 live normals plus the
+                            // Philox / transform state do not fit, 108-148 B per lane spill into the step loop, -10 % (profiles/r03_lab_n64.txt)
 #endif
 #ifndef MCP_EXP_VKEYS
 #define MCP_EXP_VKEYS 1
@@ -208,9 +209,6 @@ mc_paths_kernel(const PathArgs a) {
           philox4x32_10(blk, 0u, plo[e], phi[e], ks, x);
           block_normals<NATIVE>(x, s_tab, kc, z[e][0 * NB + q], z[e][1 * NB + q], z[e][2 * NB + q], z[e][3 * NB + q]);
         }
-#ifdef MCP_EXP_BLOCK_FENCE
-        if constexpr (NB > 4) __builtin_amdgcn_sched_barrier(0);   // experiment: one Philox block at a time (register pressure at N > 16)
-#endif
       }
       float rho[PPT][KT];
       if constexpr (FOLD) {
