@@ -242,8 +242,16 @@ __global__ void __launch_bounds__(PATH_BLOCK, (MT <= 2 && NB <= 4) ? MCP_SHARED_
   cfloat_p Lp = mu + N4;
   const float* __restrict__ Wg = a.packed + N4 + N4 * (N4 / 2 + 1);
 
+  // MCP_SWEEP_PIPE=1 (experiment, N <= 16; measured: bit-identical, 0.4 % SLOWER, profiles/r03_lab_pipe.txt -- the barriers are
+  // not where the time goes): the step software-pipelined over three steps -- at iteration t a wave draws its share of step t+2,
+  // does its row pairs of step t+1 and the matrix work of step t -- so that every hand-off between waves crosses exactly ONE
+  // barrier (double-buffered z and r images) instead of two barriers per step.
+#ifndef MCP_SWEEP_PIPE
+#define MCP_SWEEP_PIPE 0
+#endif
+  constexpr bool PIPE = MCP_SWEEP_PIPE && NB <= 4;
   __shared__ float4 s_tab[ICDF_LDS_ENTRIES];
-  __shared__ float s_z[N4][64], s_r[N4][64];
+  __shared__ float s_z[PIPE ? 2 : 1][N4][64], s_r[PIPE ? 2 : 1][N4][64];
   if constexpr (!NATIVE) {
     for (int i = threadIdx.x; i < ICDF_ENTRIES; i += PATH_BLOCK) s_tab[ICDF_PAD + i] = a.tables[i];
   }
@@ -272,9 +280,8 @@ __global__ void __launch_bounds__(PATH_BLOCK, (MT <= 2 && NB <= 4) ? MCP_SHARED_
 #pragma unroll
       for (int r = 0; r < 16; r++) V[mt][nt][r] = logc ? 0.0f : a.v0;
 
-  for (int t = 0; t < a.n_steps; t++) {
-    asm volatile("" : "+s"(mu), "+s"(Lp));
-    // phase A: this wave's share of the normals
+  // phase A: this wave's share of the normals of step t -> z image
+  auto phase_a = [&](int t, float (*zb)[64]) {
 #pragma unroll
     for (int q0 = 0; q0 < NB; q0 += 4) {
       const int q = q0 + wave;                                      // wave-uniform
@@ -283,16 +290,15 @@ __global__ void __launch_bounds__(PATH_BLOCK, (MT <= 2 && NB <= 4) ? MCP_SHARED_
         philox4x32_10((uint32_t)t * NB + q, 0u, plo, phi, ks, x);
         float z0, z1, z2, z3;
         block_normals<NATIVE>(x, s_tab, kc, z0, z1, z2, z3);
-        s_z[0 * NB + q][lane] = z0;
-        s_z[1 * NB + q][lane] = z1;
-        s_z[2 * NB + q][lane] = z2;
-        s_z[3 * NB + q][lane] = z3;
+        zb[0 * NB + q][lane] = z0;
+        zb[1 * NB + q][lane] = z1;
+        zb[2 * NB + q][lane] = z2;
+        zb[3 * NB + q][lane] = z3;
       }
     }
-#ifndef MCP_EXP_NOBARRIER     // experiment only (wrong results): what the two barriers per step cost
-    __syncthreads();
-#endif
-    // phase B: this wave's row pairs of r = mu + L z
+  };
+  // phase B: this wave's row pairs of r = mu + L z -> r image
+  auto phase_b = [&](const float (*zb)[64], float (*rb)[64]) {
 #pragma unroll
     for (int m0 = 0; m0 < N4 / 2; m0 += 4) {
 #pragma unroll
@@ -303,23 +309,22 @@ __global__ void __launch_bounds__(PATH_BLOCK, (MT <= 2 && NB <= 4) ? MCP_SHARED_
 #pragma unroll
           for (int j = 0; j <= 2 * m + 1; j++) {
             const f32x2 l2 = {Lp[2 * m * (m + 1) + 2 * j], Lp[2 * m * (m + 1) + 2 * j + 1]};
-            const float zj = s_z[j][lane];
+            const float zj = zb[j][lane];
             acc = __builtin_elementwise_fma(l2, (f32x2){zj, zj}, acc);
           }
-          s_r[2 * m][lane] = acc.x;
-          s_r[2 * m + 1][lane] = acc.y;
+          rb[2 * m][lane] = acc.x;
+          rb[2 * m + 1][lane] = acc.y;
         }
       }
     }
-#ifndef MCP_EXP_NOBARRIER
-    __syncthreads();
-#endif
-    // phase C: rho = W . r on the matrix cores, then compounding
+  };
+  // phase C: rho = W . r on the matrix cores, then compounding
+  auto phase_c = [&](const float (*rb)[64]) {
     float b[2][KS];
 #pragma unroll
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-      for (int kk = 0; kk < KS; kk++) b[nt][kk] = s_r[2 * kk + (lane >> 5)][32 * nt + (lane & 31)];
+      for (int kk = 0; kk < KS; kk++) b[nt][kk] = rb[2 * kk + (lane >> 5)][32 * nt + (lane & 31)];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
 #pragma unroll
@@ -330,6 +335,35 @@ __global__ void __launch_bounds__(PATH_BLOCK, (MT <= 2 && NB <= 4) ? MCP_SHARED_
         if constexpr (logc) V[mt][nt] = V[mt][nt] + rho;
         else V[mt][nt] = __builtin_elementwise_fma(V[mt][nt], rho, V[mt][nt]);      // 8 v_pk_fma_f32
       }
+    }
+  };
+
+  const int T = a.n_steps;
+  if constexpr (PIPE) {
+    if (T > 0) phase_a(0, s_z[0]);
+    if (T > 1) phase_a(1, s_z[1]);
+    __syncthreads();
+    if (T > 0) phase_b(s_z[0], s_r[0]);
+    __syncthreads();
+    for (int t = 0; t < T; t++) {
+      asm volatile("" : "+s"(mu), "+s"(Lp));
+      if (t + 2 < T) phase_a(t + 2, s_z[t & 1]);                 // z(t+2) replaces z(t), whose last readers passed the barrier below
+      if (t + 1 < T) phase_b(s_z[(t + 1) & 1], s_r[(t + 1) & 1]);
+      phase_c(s_r[t & 1]);
+      __syncthreads();
+    }
+  } else {
+    for (int t = 0; t < T; t++) {
+      asm volatile("" : "+s"(mu), "+s"(Lp));
+      phase_a(t, s_z[0]);
+#ifndef MCP_EXP_NOBARRIER     // experiment only (wrong results): what the two barriers per step cost
+      __syncthreads();
+#endif
+      phase_b(s_z[0], s_r[0]);
+#ifndef MCP_EXP_NOBARRIER
+      __syncthreads();
+#endif
+      phase_c(s_r[0]);
     }
   }
 

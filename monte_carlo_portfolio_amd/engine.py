@@ -213,6 +213,7 @@ class PathEngine:
                 self.s_paths = [torch.cuda.Stream(self.device) for _ in range(n_ps)]
             ns = max(1, min(int(n_stats_streams), self.n_buf))
             pool = [[torch.cuda.Stream(self.device, priority=-1) for _ in range(self.S)] for _ in range(ns)]
+            self._stat_pool = pool
             self.s_stats = [pool[i % ns] for i in range(self.n_buf)]          # buffer i -> statistics stream i % ns (per shard)
             self.ev_paths = [[torch.cuda.Event() for _ in range(self.S)] for _ in range(self.n_buf)]
             self.ev_stats = [[torch.cuda.Event() for _ in range(self.S)] for _ in range(self.n_buf)]
@@ -400,7 +401,7 @@ class PathEngine:
         if self.pipeline:
             for sp in self.s_paths:
                 sp.synchronize()
-            for row in self.s_stats[:max(1, min(len(self.s_stats), 8))]:
+            for row in self._stat_pool:
                 for ss in row:
                     ss.synchronize()
         elif self.device.type == "cuda":
