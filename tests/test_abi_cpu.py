@@ -244,3 +244,20 @@ def test_hip_errors_have_their_own_code():
     assert "MCP_E_HIP = -5" in text and "MCP_E_COMM = -6" in text
     src = open(os.path.join(ROOT, "monte_carlo_portfolio_amd", "csrc", "mcp_api.cpp")).read()
     assert "return fail(MCP_E_HIP, \"%s: %s\", #expr" in src
+
+
+def test_committed_issue_model_matches_the_kernel_at_head(tmp_path):
+    """profiles/issue_model.json (what bench.py prices roofline.issue_model with) must be the instruction mix of the step loop
+    the library is built from: regenerate it from the hipcc -S listing (no GPU needed) and compare counts and cycles."""
+    import json
+    import subprocess
+    import sys
+    out = tmp_path / "im.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "issue_model.py"), "--clock-hz", "2.303e9", "-o", str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    fresh, committed = json.load(open(out)), json.load(open(os.path.join(ROOT, "profiles", "issue_model.json")))
+    assert fresh["valu_insts_per_wave_step"] == committed["valu_insts_per_wave_step"] == 404
+    assert fresh["cycles_per_wave_step"] == pytest.approx(committed["cycles_per_wave_step"], rel=1e-12)
+    assert {(x["inst"], x["count"]) for x in fresh["rows"]} == {(x["inst"], x["count"]) for x in committed["rows"]}
+    assert committed["clock_hz"] == pytest.approx(2.303e9) and "r03_clock" in committed["clock_source"]
