@@ -109,6 +109,20 @@ def test_skewed_schedule_two_ranks_many_steps(tmp_path):
             assert float.fromhex(a[key]) == pytest.approx(float.fromhex(b[key]), rel=1e-13)
 
 
+def test_three_ranks_skewed_with_ragged_shards(tmp_path):
+    """world_size 3 (an odd world, shards of 1,001 paths each), skewed schedule, five batches: every rank ends with the
+    statistics of the union, equal to one rank holding all 3,003 paths."""
+    N, T, n_local, K = 5, 9, 1001, 1
+    three = run_world(tmp_path, 3, N, T, n_local, K, steps=5, extra={"skew": True}, tag="t3")
+    one = run_world(tmp_path, 1, N, T, 3 * n_local, K)
+    assert three[0] == three[1] == three[2]
+    a, b = three[0][0], one[0][0]
+    for key in ("n", "n_tail", "var", "x_lo", "x_hi", "min", "max"):
+        assert a[key] == b[key], key
+    for key in ("mean", "std", "sharpe", "cvar"):
+        assert float.fromhex(a[key]) == pytest.approx(float.fromhex(b[key]), rel=1e-13)
+
+
 @pytest.mark.parametrize("shards,skew", [(3, True), (2, False), (8, True)])
 def test_logical_shards_equal_one_shard(shards, skew):
     """logical_shards: one process splits its path range over S shards that exchange through the sum kernel and record
