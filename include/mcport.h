@@ -184,7 +184,8 @@ size_t mcp_packed_len(int n_assets, int n_portfolios);
 /* Pack mu, lower(chol), W (and portfolio 0's fold block) into the padded device layout (host side, no GPU needed). */
 int mcp_pack_params(int n_assets, int n_portfolios, const float *mu, const float *chol, const float *W,
                     float *packed_out, size_t packed_len);
-/* The shift of the moments, one per portfolio (host side, binary64 from the binary32 inputs): the analytic mean of x,
+/* The shift of the moments, one per portfolio (host side, binary64 from the binary32 inputs): the analytic mean of x --
+ * w_k.mu is the per-step `port_return` of app.py:708, |L^T w_k|^2 the per-step `port_std`^2 of app.py:709 --
  *   simple: c_k = (1 + w_k.mu)^T - 1          log: c_k = expm1(T (w_k.mu + |L^T w_k|^2 / 2)).
  * A function of the inputs only, hence identical on every rank; 0 where it is not finite. */
 int mcp_pivots(const mcp_params *prm, const float *mu, const float *chol, const float *W, double *pivots_out /* [K] */);
