@@ -304,7 +304,10 @@ __global__ void __launch_bounds__(PATH_BLOCK, (MT <= 2 && NB <= 4) ? MCP_SHARED_
 #pragma unroll
       for (int wv = 0; wv < 4; wv++) {                              // unrolled so that m is a compile-time constant
         const int m = m0 + wv;
-        if (m < N4 / 2 && wv == wave) {
+        // pair m costs 2m + 2 fmas: within a group of 8 pairs wave w takes pairs w and 7 - w (18 fmas for every wave) instead of
+        // w and w + 4 (12 ... 24): +0.25 % at N = 16, +1.0 % at N = 64 (profiles/r03_lab_wide.txt, "unbal" = the old assignment)
+        const int owner = (m0 & 4) ? 3 - wv : wv;
+        if (m < N4 / 2 && owner == wave) {
           f32x2 acc = {mu[2 * m], mu[2 * m + 1]};
 #pragma unroll
           for (int j = 0; j <= 2 * m + 1; j++) {
