@@ -96,8 +96,8 @@ class HipKernels:
 
 class PathEngine:
     """One rank's pipeline.  `step()` enqueues one full pass; with `pipeline=True` (default on a GPU) batches are
-    multi-buffered over HIP streams: alternating path streams, and one statistics stream per buffer (and logical shard),
-    so the tails of different batches overlap each other and the next path kernel."""
+    multi-buffered over HIP streams: alternating path streams, and a small pool of statistics streams (`n_stats_streams` per
+    logical shard, shared by the buffers modulo), so the tails of different batches overlap each other and the next path kernel."""
 
     N_STAGES = 4
 
@@ -196,7 +196,7 @@ class PathEngine:
         self.last = 0                                  # buffer of the most recent COMPLETE batch
         if self.pipeline:
             # alternating path streams: the next batch's path kernel fills the CUs that the previous one's last
-            # (partial) round of waves leaves idle; one statistics stream per buffer and shard
+            # (partial) round of waves leaves idle; statistics streams from a pool of n_stats_streams per shard (see above)
             n_ps = max(1, min(int(os.environ.get("MCP_ENGINE_PATH_STREAMS", "2")), self.n_buf * self.S))
             self.cu_reserve = int(cu_reserve)
             self._raw_streams = []
